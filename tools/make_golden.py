@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference's own Python files in this container.
+
+Only the build container has /root/reference; the GPU box does not.  This script loads the parts
+of the reference that import here *from where they lie* -- nothing is copied -- and
+stores plain input/output tensors:
+
+  kat_solver.npz   the A, b of reference tests/metrics/test_solver.py and the ScipyLsqSolver answer
+  span_*.npz       reference metrics/ops/span.py + registry.py (GRASPQP_SCIPY): inputs -> F, svd, E_fc, x
+  energy_*.npz     reference core/energy.py::calculate_energy composed over the oracle models
+  mala_*.npz       reference core/optimizer.py::MalaStar driven through the fit.py loop order for a
+                   few iterations on the oracle models, with every torch.rand/randint draw recorded
+
+qpth / TorchSDF / pytorch_kinematics / roma are not importable, so E_fc inside energy_/mala_
+fixtures uses the oracle's PDIPM restatement (that part stays "parity unpinned"); what these
+fixtures pin is everything *around* it: loop order, optimizer state handling, energy formulas.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+REF = os.environ.get("GRASPQP_REFERENCE", "/root/reference")
+SRC = os.path.join(REF, "graspqp", "src", "graspqp")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np
+import torch
+
+# graspqp_amd data helpers without importing the HIP-backed package __init__
+_pkg = types.ModuleType("graspqp_amd")
+_pkg.__path__ = [os.path.join(ROOT, "graspqp_amd")]
+sys.modules.setdefault("graspqp_amd", _pkg)
+from graspqp_amd.hands import get_hand_spec  # noqa: E402
+from graspqp_amd.utils import meshes  # noqa: E402
+
+import ref_cpu  # noqa: E402
+from ref_cpu import models as omodels  # noqa: E402
+from ref_cpu import span as ospan  # noqa: E402
+
+
+def load_ref(mod_name, rel_path):
+    spec = importlib.util.spec_from_file_location(mod_name, os.path.join(SRC, rel_path))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[mod_name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def ref_metrics():
+    """Import reference metrics/ops/{span,registry}.py with the reference's ScipyLsqSolver standing in
+    for the qpth-backed class that span.py imports unconditionally."""
+    for name, path in (
+        ("graspqp", SRC),
+        ("graspqp.metrics", os.path.join(SRC, "metrics")),
+        ("graspqp.metrics.solver", os.path.join(SRC, "metrics", "solver")),
+        ("graspqp.metrics.ops", os.path.join(SRC, "metrics", "ops")),
+    ):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    scipy_solver = load_ref("graspqp.metrics.solver.scipy_solver", "metrics/solver/scipy_solver.py")
+    stub = types.ModuleType("graspqp.metrics.solver.qp_solver")
+    stub.SQPLsqSolver = scipy_solver.ScipyLsqSolver
+    sys.modules["graspqp.metrics.solver.qp_solver"] = stub
+    registry = importlib.import_module("graspqp.metrics.ops.registry")
+    return scipy_solver, registry
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def gen_kat(scipy_solver):
+    A = torch.Tensor(
+        [
+            [-0.0, 0.25819889, 0.25819889, -0.25819889, -0.25819889, -0.25819889],
+            [0.31622777, -0.18257419, -0.18257419, -0.18257419, -0.18257419, -0.18257419],
+            [0.02810913, -0.09128826, 0.10345754, 0.13997471, -0.05477109, -0.10345754],
+        ]
+    ).unsqueeze(0)
+    b = torch.Tensor([0.25819889, 0.18257419, 0.00608464]).unsqueeze(0)
+    solver = scipy_solver.ScipyLsqSolver.from_mat(A, b)
+    val, x = solver(A, b, min_bound=-10.0, max_bound=1e3, init=0.1, return_solution=True)
+    np.savez(os.path.join(OUT, "kat_solver.npz"), A=A.numpy(), b=b.numpy(), value=val.numpy(), x=x.numpy(),
+             min_bound=-10.0, max_bound=1e3)
+    print("kat value", val)
+
+
+def gen_span(registry):
+    MT = registry.GraspSpanMetricFactory.MetricType
+    for n, k, B, seed in ((4, 4, 16, 0), (12, 4, 32, 1), (16, 4, 16, 2), (12, 8, 16, 3)):
+        torch.manual_seed(seed)
+        # contacts roughly on a 5 cm object, normals roughly outward + noise (some near the b1 flip zone)
+        # the reference metric is float32-only (b1 is built as float32, span.py:271-273)
+        d = torch.nn.functional.normalize(torch.randn(B, n, 3), dim=-1)
+        pts = d * (0.05 + 0.01 * torch.randn(B, n, 1))
+        nrm = torch.nn.functional.normalize(d + 0.3 * torch.randn(B, n, 3), dim=-1)
+        nrm[0, 0] = torch.tensor([1.0, 1.0, 1.0]) / 3**0.5  # exercises dot > 0.9 branch
+        cog = 0.005 * torch.randn(B, 3)
+        fn = registry.GraspSpanMetricFactory.create(
+            MT.GRASPQP_SCIPY, solver_kwargs={"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": k}
+        )
+        pts_r = pts.clone().requires_grad_()
+        e, x = fn(contact_pts=pts_r, contact_normals=nrm, sdf=None, cog=cog, with_solution=True, svd_gain=0.1)
+        F = fn.metric._cache["F"]
+        svd = (torch.linalg.svdvals(F)).prod(-1) ** (1 / 6)
+        np.savez(
+            os.path.join(OUT, f"span_n{n}_k{k}.npz"),
+            **to_np(dict(contact_pts=pts, contact_normals=nrm, cog=cog, F=F, svd=svd, e_fc=e, x_sum=x,
+                         friction=0.2, max_limit=20.0, n_cone_vecs=k, svd_gain=0.1)),
+        )
+        print(f"span n={n} k={k}: F{tuple(F.shape)} e_fc[0:3]={e[:3].tolist()}")
+
+
+class _FcAdapter:
+    """energy_fnc with the reference calling convention, backed by the oracle PDIPM."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __call__(self, contact_pts, contact_normals, sdf, cog, with_solution=True, svd_gain=0.1):
+        return ospan.e_fc(contact_pts, contact_normals, cog, svd_gain=svd_gain, **self.kw)
+
+
+def make_scene(hand_name, n_obj, batch_each, n_contact, dtype, seed, mesh="sphere", n_surface=2500):
+    spec = get_hand_spec(hand_name)
+    hand = omodels.OracleHand(spec, dtype=dtype)
+    fvs, sps = [], []
+    for i in range(n_obj):
+        fv = meshes.icosphere(3, 0.05) if mesh == "sphere" else meshes.superquadric(seed + i, 48, 24)
+        fvs.append(fv)
+        sps.append(meshes.surface_points(fv, n_surface, oversample=8, seed=42))
+    obj = omodels.OracleObject(fvs, sps, batch_each, dtype=dtype)
+    B = n_obj * batch_each
+    g = torch.Generator().manual_seed(seed)
+    # hand ~12-16 cm from the object centre, palm roughly facing it, joints = default + jitter
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g, dtype=torch.float64), dim=-1)
+    t = dirs * (0.10 + 0.04 * torch.rand(B, 1, generator=g, dtype=torch.float64))
+    six = torch.randn(B, 6, generator=g, dtype=torch.float64)
+    th = torch.as_tensor(spec.default_state, dtype=torch.float64)[None] + 0.15 * torch.randn(
+        B, spec.n_dofs, generator=g, dtype=torch.float64
+    )
+    hp = torch.cat([t, six, th], dim=1).to(dtype)
+    idx = torch.randint(spec.n_contact_candidates, (B, n_contact), generator=g)
+    return spec, hand, obj, hp, idx, fvs, sps
+
+
+def gen_energy(ref_energy):
+    for tag, hand_name, n_obj, be, n, mesh, seed in (
+        ("allegro_sphere_b4_n4", "allegro", 1, 4, 4, "sphere", 11),
+        ("allegro_sq_b6_n12", "allegro", 2, 3, 12, "sq", 12),
+    ):
+        spec, hand, obj, hp, idx, fvs, sps = make_scene(hand_name, n_obj, be, n, torch.float64, seed, mesh, n_surface=600)
+        # push one row into the object so that E_pen / E_dis-inside branches are exercised
+        hp[0, :3] *= 0.35
+        hp = hp.clone().requires_grad_()
+        hand.set_parameters(hp, idx)
+        losses = ref_energy.calculate_energy(
+            hand, obj, energy_fnc=_FcAdapter(mu=0.2, k=4, max_limit=20.0),
+            energy_names=["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"], method="gendexgrasp", svd_gain=0.1,
+        )
+        w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+        tot = sum(w[k] * v for k, v in losses.items())
+        tot.sum().backward()
+        out = dict(hand_pose=hp, contact_idx=idx, total=tot, grad=hand.hand_pose.grad,
+                   batch_size_each=be, n_obj=n_obj)
+        for k, v in losses.items():
+            out[k] = v
+        for i in range(n_obj):
+            out[f"obj{i}_face_verts"] = fvs[i]
+            out[f"obj{i}_surface_points"] = sps[i]
+        np.savez_compressed(os.path.join(OUT, f"energy_{tag}.npz"), **to_np(out))
+        print(f"energy {tag}:", {k: v.detach().numpy().round(5).tolist() for k, v in losses.items()})
+
+
+class _Recorder:
+    """Records every torch.rand / torch.randint result while active."""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._rand, self._randint = torch.rand, torch.randint
+
+        def rand(*a, **k):
+            r = self._rand(*a, **k)
+            self.log.append(("rand", r.clone()))
+            return r
+
+        def randint(*a, **k):
+            r = self._randint(*a, **k)
+            self.log.append(("randint", r.clone()))
+            return r
+
+        torch.rand, torch.randint = rand, randint
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randint = self._rand, self._randint
+
+
+def gen_mala(ref_energy, ref_opt):
+    tag, hand_name, n_obj, be, n, seed, n_steps = "allegro_sphere_b8_n4", "allegro", 2, 4, 4, 21, 5
+    dtype = torch.float32
+    spec, hand, obj, hp, idx, fvs, sps = make_scene(hand_name, n_obj, be, n, dtype, seed, "sphere", n_surface=400)
+    B = n_obj * be
+    hp0 = hp.clone().requires_grad_()
+    hand.set_parameters(hp0, idx)
+    fc = _FcAdapter(mu=0.2, k=4, max_limit=20.0)
+    names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"]
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    opt = ref_opt.MalaStar(hand, switch_possibility=0.4, starting_temperature=18, temperature_decay=0.95,
+                           annealing_period=30, step_size=0.005, stepsize_period=50, mu=0.98, device="cpu",
+                           batch_size=be, clip_grad=False)
+
+    def total(losses):
+        return sum(w[k] * v for k, v in losses.items())
+
+    # fit.py:381-396
+    losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+    energy = total(losses)
+    energy.sum().backward()
+    out = dict(hand_pose0=hand.hand_pose.detach().clone(), contact_idx0=idx.clone(), energy0=energy.detach().clone(),
+               grad0=hand.hand_pose.grad.detach().clone(), batch_size_each=be, n_obj=n_obj, n_steps=n_steps)
+    opt.zero_grad()  # fit.py:396 -- zeroes the initial gradient
+    torch.manual_seed(seed)
+    for step in range(1, n_steps + 1):
+        with _Recorder() as rec:
+            s = opt.try_step()  # fit.py:400
+        u_switch = rec.log[0][1]
+        vals = rec.log[1][1]
+        mask = u_switch < 0.4
+        new_idx = torch.zeros(B, n, dtype=torch.long)
+        new_idx[mask] = vals
+        eb = energy.view(-1, be)  # fit.py:403-406
+        z = ((eb - eb.mean(-1).unsqueeze(-1)) / eb.std(-1).unsqueeze(-1)).view(-1)
+        opt.zero_grad()
+        new_losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+        new_energy = total(new_losses)
+        new_energy.sum().backward()
+        prop_pose = hand.hand_pose.detach().clone()
+        prop_grad = hand.hand_pose.grad.detach().clone()
+        with torch.no_grad():
+            with _Recorder() as rec2:
+                accept, T = opt.accept_step(energy, new_energy, None, z, 1.0)
+            u_acc = rec2.log[0][1]
+            energy[accept] = new_energy[accept]
+        out.update({
+            f"s{step}_u_switch": u_switch, f"s{step}_new_idx": new_idx, f"s{step}_u_accept": u_acc,
+            f"s{step}_step_size": s.detach().clone(), f"s{step}_z": z.detach().clone(),
+            f"s{step}_prop_pose": prop_pose, f"s{step}_prop_grad": prop_grad,
+            f"s{step}_new_energy": new_energy.detach().clone(), f"s{step}_accept": accept.clone(),
+            f"s{step}_temperature": T.detach().clone(),
+            f"s{step}_hand_pose": hand.hand_pose.detach().clone(),
+            f"s{step}_contact_idx": hand.contact_point_indices.clone(),
+            f"s{step}_grad": hand.hand_pose.grad.detach().clone(),
+            f"s{step}_energy": energy.detach().clone(),
+            f"s{step}_ema": opt.ema_grad_hand_pose.detach().clone(),
+        })
+        print(f"mala step {step}: accept={accept.tolist()} mean E={energy.mean().item():.4f}")
+    for i in range(n_obj):
+        out[f"obj{i}_face_verts"] = fvs[i]
+        out[f"obj{i}_surface_points"] = sps[i]
+    np.savez_compressed(os.path.join(OUT, f"mala_{tag}.npz"), **to_np(out))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    scipy_solver, registry = ref_metrics()
+    gen_kat(scipy_solver)
+    gen_span(registry)
+    ref_energy = load_ref("_ref_energy", "core/energy.py")
+    ref_opt = load_ref("_ref_optimizer", "core/optimizer.py")
+    gen_energy(ref_energy)
+    gen_mala(ref_energy, ref_opt)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""ctypes binding of libgraspqp_hip.so -- the only way compute enters this package.
+
+The prototypes are read from ``include/graspqp_hip.h`` (single source of truth for the C ABI); a test checks
+that every declared symbol is exported.  There is deliberately no fallback: if the library is missing or a call
+fails, a ``RuntimeError`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgraspqp_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "graspqp_hip.h")
+
+_SCALARS = {
+    "int": ctypes.c_int,
+    "int32_t": ctypes.c_int32,
+    "int64_t": ctypes.c_int64,
+    "float": ctypes.c_float,
+    "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object]]]:
+    """name -> (restype, argtypes) for every ``gq_*`` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"typedef struct gqHandDesc \{.*?\} gqHandDesc;", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const char\*|int)\s+(gq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = a.replace("const ", "").split(" ")[0]
+                    argtypes.append(_SCALARS[ty])
+        protos[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, argtypes)
+    return protos
+
+
+class HandDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_dofs", ctypes.c_int32),
+        ("n_links", ctypes.c_int32),
+        ("n_cand", ctypes.c_int32),
+        ("n_spheres", ctypes.c_int32),
+        ("node_parent", ctypes.c_void_p),
+        ("node_type", ctypes.c_void_p),
+        ("node_pre", ctypes.c_void_p),
+        ("node_axis", ctypes.c_void_p),
+        ("link_node", ctypes.c_void_p),
+        ("link_offset", ctypes.c_void_p),
+        ("cand_pos", ctypes.c_void_p),
+        ("cand_nrm", ctypes.c_void_p),
+        ("cand_link", ctypes.c_void_p),
+        ("sphere", ctypes.c_void_p),
+        ("sphere_link", ctypes.c_void_p),
+        ("joints_lower", ctypes.c_void_p),
+        ("joints_upper", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+_protos = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library; raises if it is not built."""
+    global _lib, _protos
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(graspqp_amd has no CPU fallback)"
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        _protos = parse_header()
+        for name, (res, args) in _protos.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def prototypes():
+    lib()
+    return _protos
+
+
+def call(name: str, *args):
+    """Call an ``int``-returning entry point; non-zero status -> RuntimeError with the library's message."""
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        msg = l.gq_last_error()
+        raise RuntimeError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
+    if not t.is_contiguous():
+        raise RuntimeError("graspqp_amd ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    return ptr(t, torch.float32)
+
+
+def i32(t):
+    return ptr(t, torch.int32)
+
+
+def i64(t):
+    return ptr(t, torch.int64)
+
+
+def u8(t):
+    return ptr(t, torch.uint8)

@@ -1,0 +1,40 @@
+"""``calculate_energy`` with the reference's signature (core/energy.py:6-89), composed from the HIP-backed ops.
+
+This is the autograd ("plugin surface") route: every term is a torch tensor whose backward runs the HIP
+backward kernels, so a ``fit.py``-style loop (``new_energy.sum().backward()``) works unchanged.  The
+``GraspStepper`` in ``graspqp_amd.stepper`` runs the same kernels without autograd for throughput.
+"""
+
+import torch
+
+
+def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[], method="gendexgrasp", svd_gain=0.1):
+    losses = {}
+    distance, contact_normal = object_model.cal_distance(hand_model.contact_points)
+    if method == "dexgraspnet":
+        losses["E_dis"] = torch.sum(distance.abs(), dim=-1, dtype=torch.float)
+    elif method == "gendexgrasp":
+        nH = hand_model.contact_normals
+        losses["E_dis"] = ((1 - torch.sum((-contact_normal) * nH, dim=-1)).exp() * distance.abs()).sum(-1)
+    else:
+        raise ValueError(f"Unknown method: {method}")
+
+    E_fc, _lambda = energy_fnc(contact_pts=hand_model.contact_points, contact_normals=contact_normal, sdf=distance,
+                               cog=object_model.cog, with_solution=True, svd_gain=svd_gain)
+    losses["E_fc"] = E_fc
+
+    th = hand_model.hand_pose[:, 9:]
+    losses["E_joints"] = torch.sum((th > hand_model.joints_upper) * (th - hand_model.joints_upper), dim=-1) + torch.sum(
+        (th < hand_model.joints_lower) * (hand_model.joints_lower - th), dim=-1
+    )
+
+    object_model.attach(hand_model)
+    distances = hand_model.cal_distance(object_model.surface_points_each)
+    distances = torch.where(distances <= 0, torch.zeros_like(distances), distances)
+    losses["E_pen"] = distances.sum(-1)
+    losses["E_spen"] = hand_model.self_penetration()
+
+    for name in ("E_prior", "E_wall", "E_manipulativity"):
+        if name in energy_names:
+            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY 8f-3)")
+    return losses

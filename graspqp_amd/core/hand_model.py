@@ -1,0 +1,128 @@
+"""HandModel with the reference's attribute/method surface (core/hand_model.py) on top of the HIP kernels.
+
+Only the hot-path part of the reference class is mirrored: ``set_parameters``, ``fk``,
+``_set_contact_idxs``, ``cal_distance``, ``self_penetration`` and the state attributes the optimizer and
+``calculate_energy`` touch.  Construction goes through a :class:`HandSpec` (flat arrays) instead of
+pytorch_kinematics / trimesh objects.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..hands import get_hand_spec
+
+
+class HandModel:
+    def __init__(self, spec, device="cuda", grasp_type=None):
+        if not str(device).startswith("cuda"):
+            raise RuntimeError("graspqp_amd.HandModel runs on the GPU only (device='cuda'); there is no CPU path")
+        self.spec = spec
+        self.device = torch.device(device)
+        self._hand = ops.HandHandle(spec)
+        self.n_dofs = spec.n_dofs
+        self.n_contact_candidates = spec.n_contact_candidates
+        self._actuated_joints_names = list(spec.joint_names)
+        self.joints_names = list(spec.joint_names)
+        self._contact_links = None
+        self.joints_lower = torch.tensor(spec.joints_lower, device=self.device)
+        self.joints_upper = torch.tensor(spec.joints_upper, device=self.device)
+        self.default_state = torch.tensor(spec.default_state, device=self.device)
+        self.forward_axis = torch.tensor(spec.forward_axis, device=self.device)
+        self.up_axis = torch.tensor(spec.up_axis, device=self.device)
+        self.grasp_axis = torch.tensor(spec.grasp_axis, device=self.device)
+        self.global_index_to_link_index = torch.tensor(spec.cand_link, dtype=torch.long, device=self.device)
+        self.hand_pose = None
+        self.contact_point_indices = None
+        self.global_translation = None
+        self.global_rotation = None
+        self.current_status = None  # (B,L,3,4) link transforms in the hand frame
+        self.contact_points = None
+        self.contact_normals = None
+        self._sphere_centers = None
+        self._fk_ws = None
+
+    # reference hand_model.py:762-766 -- returns the (B,L,3,4) link transforms (the reference returns a dict of
+    # Transform3d keyed by link name; ``link_matrix(name)`` gives the same 4x4 view).
+    def fk(self, joint_angles):
+        B = joint_angles.shape[0]
+        hp = torch.zeros(B, 9 + self.n_dofs, device=self.device)
+        hp[:, 3] = 1.0
+        hp[:, 7] = 1.0
+        hp[:, 9:] = joint_angles.detach()
+        idx = torch.zeros(B, 0, dtype=torch.long, device=self.device)
+        return ops.fk_contacts(hp, idx, self._hand)[1]
+
+    def link_matrix(self, link_name):
+        l = self.spec.link_names.index(link_name)
+        T = self.current_status[:, l]
+        bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=self.device).expand(T.shape[0], 1, 4)
+        return torch.cat([T, bottom], dim=1)
+
+    # reference hand_model.py:833-873
+    def set_parameters(self, hand_pose, contact_point_indices=None, env_mask=None):
+        if env_mask is not None:
+            with torch.no_grad():
+                self.hand_pose = torch.where(env_mask.unsqueeze(-1), hand_pose, self.hand_pose)
+            self.hand_pose.requires_grad = True
+            self.hand_pose.retain_grad()
+        else:
+            self.hand_pose = hand_pose.clone()
+        if self.hand_pose.requires_grad:
+            self.hand_pose.retain_grad()
+        if self.hand_pose.isnan().any():
+            raise ValueError("nan in hand_pose")
+        self.global_translation = self.hand_pose[:, 0:3]
+        self._set_contact_idxs(contact_point_indices, env_mask=env_mask)
+
+    # reference hand_model.py:787-831 -- only the n selected candidates are transformed (the reference
+    # transforms all C and gathers n)
+    def _set_contact_idxs(self, contact_point_indices, env_mask=None):
+        if contact_point_indices is None:
+            contact_point_indices = self.contact_point_indices
+        if isinstance(contact_point_indices, str) and contact_point_indices == "all":
+            contact_point_indices = (
+                torch.arange(self.n_contact_candidates, dtype=torch.long, device=self.device)
+                .unsqueeze(0)
+                .expand(self.hand_pose.shape[0], -1)
+            )
+        if env_mask is None or self.contact_point_indices is None:
+            self.contact_point_indices = contact_point_indices.clone()
+        else:
+            self.contact_point_indices = torch.where(env_mask.unsqueeze(-1), contact_point_indices, self.contact_point_indices)
+        Rg, LT, cp, cn, sc, ws = ops.fk_contacts(self.hand_pose, self.contact_point_indices, self._hand)
+        self._fk_ws = ws
+        self.global_rotation = Rg
+        self.current_status = LT
+        self.contact_points = cp
+        self.contact_normals = cn
+        self._sphere_centers = sc
+
+    # reference hand_model.py:875-987
+    def cal_distance(self, x):
+        """x: (B,N,3) object surface points, identical for the rows of one object (object_model.py:182-184), or the
+        un-expanded (n_obj,N,3).  Returns (B,N) max-over-links signed distance, inside positive."""
+        B = self.hand_pose.shape[0]
+        if x.shape[0] == B and B > 0:
+            # recover the per-object tensor: rows of an object share their points
+            be = getattr(self, "_batch_each_hint", None)
+            if be is None:
+                raise RuntimeError("call ObjectModel.attach(hand_model) or pass the (n_obj,N,3) surface tensor")
+            surf = x.view(-1, be, x.shape[1], 3)[:, 0].contiguous()
+        else:
+            surf = x
+            be = B // x.shape[0]
+        # the kinematic state (Rg, link transforms, FK workspace) is the one written by the last set_parameters
+        return ops.hand_pen(self.hand_pose, surf, be, self._hand, self.contact_point_indices,
+                            self.global_rotation.detach(), self.current_status.detach(), self._fk_ws,
+                            self._fk_ws.numel())
+
+    # reference hand_model.py:989-1040
+    def self_penetration(self):
+        return ops.self_pen(self._sphere_centers, self._hand)
+
+
+def get_hand_model(hand_name: str, device="cuda", asset_dir=None, **kwargs) -> HandModel:
+    """reference hands/__init__.py:27-28"""
+    return HandModel(get_hand_spec(hand_name, asset_dir), device=device, **kwargs)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libgraspqp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
+OBJS=()
+for f in api qp qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc loop; do
+  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ -n "$(find "$HERE" -name '*.h' -newer "$OUT/$f.o" 2>/dev/null)" ]; then
+    echo "[build] hipcc $f.hip"
+    "$HIPCC" $FLAGS ${GQ_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o" &
+  fi
+  OBJS+=("$OUT/$f.o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$OUT/libgraspqp_hip.so"
+echo "[build] $OUT/libgraspqp_hip.so"

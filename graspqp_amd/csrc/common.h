@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 kernels.  Wavefront = 64 lanes, hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define GQ_WAVE 64
+#define GQ_INF_F __builtin_inff()
+
+// ---- error plumbing across the C ABI (no exceptions; 0 = ok) -------------------------------------
+extern "C" void gq_set_error_(const char* msg);
+#define GQ_FAIL(code, ...)                          \
+  do {                                              \
+    char gq_buf_[512];                              \
+    snprintf(gq_buf_, sizeof(gq_buf_), __VA_ARGS__); \
+    gq_set_error_(gq_buf_);                         \
+    return (code);                                  \
+  } while (0)
+#define GQ_CHECK_HIP(expr)                                                               \
+  do {                                                                                   \
+    hipError_t gq_e_ = (expr);                                                           \
+    if (gq_e_ != hipSuccess) GQ_FAIL(3, "%s failed: %s", #expr, hipGetErrorString(gq_e_)); \
+  } while (0)
+#define GQ_REQUIRE(cond, ...) \
+  do {                        \
+    if (!(cond)) GQ_FAIL(2, __VA_ARGS__); \
+  } while (0)
+#define GQ_LAUNCH_CHECK() GQ_CHECK_HIP(hipGetLastError())
+
+enum { GQ_OK = 0, GQ_ERR_ARG = 2, GQ_ERR_HIP = 3, GQ_ERR_UNSUPPORTED = 4 };
+
+// ---- lane helpers -----------------------------------------------------------------------------------
+__device__ __forceinline__ int gq_lane() { return threadIdx.x & (GQ_WAVE - 1); }
+
+// value of `v` in lane `l` (l must be wave-uniform); result is wave-uniform (lives in an SGPR)
+__device__ __forceinline__ float gq_readlane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int gq_readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ float gq_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GQ_WAVE);
+  return v;
+}
+__device__ __forceinline__ double gq_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GQ_WAVE);
+  return v;
+}
+// NaN-propagating min / max (torch.min / torch.max semantics)
+__device__ __forceinline__ float gq_nanmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float gq_nanmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ float gq_wave_nanmin(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = gq_nanmin(v, __shfl_xor(v, o, GQ_WAVE));
+  return v;
+}
+
+// ---- small vector math --------------------------------------------------------------------------------
+struct gq3 {
+  float x, y, z;
+};
+__device__ __forceinline__ gq3 gq_mk(float x, float y, float z) { return gq3{x, y, z}; }
+__device__ __forceinline__ gq3 operator+(gq3 a, gq3 b) { return gq3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ gq3 operator-(gq3 a, gq3 b) { return gq3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ gq3 operator*(float s, gq3 a) { return gq3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float gq_dot(gq3 a, gq3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ gq3 gq_cross(gq3 a, gq3 b) {
+  return gq3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// y = M x, M row-major 3x3 at m[0..8]
+__device__ __forceinline__ gq3 gq_mv(const float* m, gq3 v) {
+  return gq3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+             m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+// y = M^T x
+__device__ __forceinline__ gq3 gq_mtv(const float* m, gq3 v) {
+  return gq3{m[0] * v.x + m[3] * v.y + m[6] * v.z, m[1] * v.x + m[4] * v.y + m[7] * v.z,
+             m[2] * v.x + m[5] * v.y + m[8] * v.z};
+}

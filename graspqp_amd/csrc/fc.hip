@@ -1,0 +1,394 @@
+// Force-closure energy of GraspQP as fused kernels around the batched box-QP:
+//   friction-cone edges + grasp matrix F (reference metrics/ops/span.py:263-295, 341-346),
+//   E_fc = 2 (1/2 |F x|^2 + 0.01) exp(-gain (prod sigma_i(F))^(1/6))  (span.py:402, registry.py:82-87),
+// and its gradient with respect to the contact points (contact normals come from the object SDF and are
+// constants for autograd, object_model.py:246).
+#include "common.h"
+
+extern "C" int gq_lsq_boxqp_forward(const float*, const float*, const float*, const float*, float, float, int64_t, int,
+                                    int, float, float, int, int, float*, float*, float*, int32_t*, int32_t*, void*,
+                                    size_t, void*);
+extern "C" int gq_lsq_boxqp_backward(const float*, const float*, const float*, const float*, int64_t, int, int, float,
+                                     float*, float*, void*);
+extern "C" int gq_boxqp_workspace_bytes(int64_t, int, int, size_t*);
+
+struct GqCone {
+  gq3 f;    // cone edge (already divided by k)
+  gq3 tau;  // torque_weight * (r x f)
+  gq3 r;
+};
+
+// column i = contact c = i / k, edge e = i % k
+__device__ __forceinline__ GqCone gq_cone_column(const float* cp, const float* cn, const float* cog, int c, int e, int k,
+                                                 float mu, float tw) {
+  const gq3 n = gq_mk(cn[c * 3], cn[c * 3 + 1], cn[c * 3 + 2]);
+  const gq3 p = gq_mk(cp[c * 3], cp[c * 3 + 1], cp[c * 3 + 2]);
+  const float is3 = 0.57735026918962576f;
+  gq3 b1 = gq_mk(is3, is3, is3);
+  const float dot = (b1.x * n.x + b1.y * n.y + b1.z * n.z) * 1.0f / (sqrtf(gq_dot(n, n)) + 1e-6f);
+  if (dot > 0.9f) b1.y -= 2.0f;
+  const gq3 t1 = gq_cross(n, b1);
+  const gq3 t2 = gq_cross(n, t1);
+  const float cc = sqrtf(1.0f - mu * mu);
+  gq3 dir;
+  if (k == 4) {
+    const float s = (e < 2) ? mu : -mu;
+    dir = (e & 1) ? (s * t2) : (s * t1);
+  } else {
+    const float ang = 6.283185307179586f / (float)k * (float)e;
+    dir = mu * (cosf(ang) * t1 + sinf(ang) * t2);
+  }
+  GqCone o;
+  o.f = (1.0f / (float)k) * (dir + cc * n);
+  o.r = p - gq_mk(cog[0], cog[1], cog[2]);
+  o.tau = tw * gq_cross(o.r, o.f);
+  return o;
+}
+
+__global__ void gq_grasp_matrix_kernel(const float* __restrict__ cpts, const float* __restrict__ cnrm,
+                                       const float* __restrict__ cog, int B, int n, int k, float mu, float tw,
+                                       float* __restrict__ F) {
+  const int nz = n * k;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)B * nz) return;
+  const int row = (int)(t / nz), i = (int)(t % nz);
+  const GqCone c = gq_cone_column(cpts + (size_t)row * n * 3, cnrm + (size_t)row * n * 3, cog + (size_t)row * 3, i / k,
+                                  i % k, k, mu, tw);
+  float* o = F + (size_t)row * 6 * nz + i;
+  o[0] = c.f.x;
+  o[nz] = c.f.y;
+  o[2 * nz] = c.f.z;
+  o[3 * nz] = c.tau.x;
+  o[4 * nz] = c.tau.y;
+  o[5 * nz] = c.tau.z;
+}
+
+// 6x6 SPD Cholesky in double (every lane redundantly); returns false if not positive definite
+__device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21]) {
+  // packed lower triangle: idx(i,j) = i(i+1)/2 + j
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = G[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) s -= Lm[i * (i + 1) / 2 + t] * Lm[j * (j + 1) / 2 + t];
+      if (i == j) {
+        if (!(s > 0.0)) {
+          ok = false;
+          s = 1.0;
+        }
+        Lm[i * (i + 1) / 2 + j] = sqrt(s);
+      } else {
+        Lm[i * (i + 1) / 2 + j] = s / Lm[j * (j + 1) / 2 + j];
+      }
+    }
+  }
+  return ok;
+}
+
+struct GqFcArgs {
+  const float* F;     // (B,6,nz)
+  const float* x;     // (B,nz)
+  int B, n, k;
+  float svd_gain, values_gain, eps_add;
+  float* e_fc;   // (B)
+  float* val;    // (B)
+  float* svd;    // (B)
+  float* Ftr;    // (B,nz)  f_i . (F x)
+  float* x_sum;  // (B,n) or null
+};
+
+__global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
+  const int row = blockIdx.x, lane = gq_lane();
+  const int nz = g.n * g.k;
+  double gr[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) gr[i] = 0.0;
+  float r[6] = {0, 0, 0, 0, 0, 0};
+  // nz may exceed 64: lanes stride over the columns
+  for (int i = lane; i < nz; i += GQ_WAVE) {
+    float f[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f[q] = g.F[((size_t)row * 6 + q) * nz + i];
+    const float xi = g.x[(size_t)row * nz + i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      r[a] = fmaf(f[a], xi, r[a]);
+#pragma unroll
+      for (int b = 0; b <= a; ++b) gr[a * (a + 1) / 2 + b] += (double)f[a] * (double)f[b];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) r[a] = gq_wave_sum(r[a]);
+#pragma unroll
+  for (int i = 0; i < 21; ++i) gr[i] = gq_wave_sum_d(gr[i]);
+  double Lm[21];
+  const bool ok = gq_chol6(gr, Lm);
+  double lp = 1.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) lp *= Lm[i * (i + 1) / 2 + i];
+  const float svd = ok ? (float)pow(lp, 1.0 / 6.0) : 0.0f;  // (prod sigma)^(1/6) = det(F F')^(1/12)
+  float val = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) val = fmaf(r[a], r[a], val);
+  val *= 0.5f;
+  for (int i = lane; i < nz; i += GQ_WAVE) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc = fmaf(g.F[((size_t)row * 6 + q) * nz + i], r[q], acc);
+    g.Ftr[(size_t)row * nz + i] = acc;
+  }
+  if (g.x_sum) {
+    for (int c = lane; c < g.n; c += GQ_WAVE) {
+      float s = 0.0f;
+      for (int e = 0; e < g.k; ++e) s += g.x[(size_t)row * nz + c * g.k + e];
+      g.x_sum[(size_t)row * g.n + c] = s;
+    }
+  }
+  if (lane == 0) {
+    g.val[row] = val;
+    g.svd[row] = svd;
+    g.e_fc[row] = g.values_gain * (val + g.eps_add) * expf(-g.svd_gain * svd);
+  }
+}
+
+__global__ void gq_fc_dldx_kernel(const float* __restrict__ g_e, const float* __restrict__ svd,
+                                  const float* __restrict__ Ftr, int B, int nz, float svd_gain, float values_gain,
+                                  float* __restrict__ dl_dx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)B * nz) return;
+  const int row = (int)(t / nz);
+  const float gval = g_e[row] * values_gain * expf(-svd_gain * svd[row]);
+  dl_dx[t] = gval * Ftr[t];
+}
+
+struct GqFcBwdArgs {
+  const float* F;
+  const float* x;
+  const float* dx;  // (B,nz) from the QP backward
+  const float* cpts;
+  const float* cnrm;
+  const float* cog;
+  const float* g_e;
+  const float* val;
+  const float* svd;
+  int B, n, k;
+  float mu, tw, svd_gain, values_gain, eps_add;
+  float* g_cpts;  // (B,n,3)
+};
+
+__global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
+  extern __shared__ float sh[];  // nz*3 per-column contributions
+  const int row = blockIdx.x, lane = gq_lane();
+  const int nz = g.n * g.k;
+  double gr[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) gr[i] = 0.0;
+  float r[6] = {0, 0, 0, 0, 0, 0}, fd[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < nz; i += GQ_WAVE) {
+    float f[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f[q] = g.F[((size_t)row * 6 + q) * nz + i];
+    const float xi = g.x[(size_t)row * nz + i], di = g.dx[(size_t)row * nz + i];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      r[a] = fmaf(f[a], xi, r[a]);
+      fd[a] = fmaf(f[a], di, fd[a]);
+#pragma unroll
+      for (int b = 0; b <= a; ++b) gr[a * (a + 1) / 2 + b] += (double)f[a] * (double)f[b];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    r[a] = gq_wave_sum(r[a]);
+    fd[a] = gq_wave_sum(fd[a]);
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) gr[i] = gq_wave_sum_d(gr[i]);
+  double Lm[21];
+  const bool ok = gq_chol6(gr, Lm);
+  const float ge = g.g_e[row], svd = g.svd[row], val = g.val[row];
+  const float ex = expf(-g.svd_gain * svd);
+  const float gval = ge * g.values_gain * ex;
+  const float gsvd = ok ? ge * g.values_gain * (val + g.eps_add) * ex * (-g.svd_gain) : 0.0f;
+  const float* cp = g.cpts + (size_t)row * g.n * 3;
+  const float* cn = g.cnrm + (size_t)row * g.n * 3;
+  const float* cog = g.cog + (size_t)row * 3;
+  for (int i = lane; i < nz; i += GQ_WAVE) {
+    const GqCone c = gq_cone_column(cp, cn, cog, i / g.k, i % g.k, g.k, g.mu, g.tw);
+    const float xi = g.x[(size_t)row * nz + i], di = g.dx[(size_t)row * nz + i];
+    // d(prod sigma^(1/6))/dF = svd/6 * (F F')^-1 F : solve L L' w = f_i
+    double w[6] = {c.f.x, c.f.y, c.f.z, c.tau.x, c.tau.y, c.tau.z};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int t = 0; t < a; ++t) w[a] -= Lm[a * (a + 1) / 2 + t] * w[t];
+      w[a] /= Lm[a * (a + 1) / 2 + a];
+    }
+#pragma unroll
+    for (int a = 5; a >= 0; --a) {
+#pragma unroll
+      for (int t = a + 1; t < 6; ++t) w[a] -= Lm[t * (t + 1) / 2 + a] * w[t];
+      w[a] /= Lm[a * (a + 1) / 2 + a];
+    }
+    // gradient wrt the torque rows of column i (rows 3..5)
+    gq3 gt;
+    const float s6 = gsvd * svd / 6.0f;
+    gt.x = (gval * r[3] + fd[3]) * xi + r[3] * di + s6 * (float)w[3];
+    gt.y = (gval * r[4] + fd[4]) * xi + r[4] * di + s6 * (float)w[4];
+    gt.z = (gval * r[5] + fd[5]) * xi + r[5] * di + s6 * (float)w[5];
+    // tau = tw (r x f)  ->  d/dr = tw (f x g_tau)
+    const gq3 gp = g.tw * gq_cross(c.f, gt);
+    sh[i * 3] = gp.x;
+    sh[i * 3 + 1] = gp.y;
+    sh[i * 3 + 2] = gp.z;
+  }
+  __syncthreads();
+  for (int c = lane; c < g.n; c += GQ_WAVE) {
+    float sx = 0, sy = 0, sz = 0;
+    for (int e = 0; e < g.k; ++e) {
+      sx += sh[(c * g.k + e) * 3];
+      sy += sh[(c * g.k + e) * 3 + 1];
+      sz += sh[(c * g.k + e) * 3 + 2];
+    }
+    float* o = g.g_cpts + ((size_t)row * g.n + c) * 3;
+    o[0] = sx;
+    o[1] = sy;
+    o[2] = sz;
+  }
+}
+
+static size_t gq_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" {
+
+// workspace = F (B,6,nz) + x,lam,slack + Ftr + dl_dx + dx + dlam + val + svd + QP workspace
+int gq_fc_workspace_bytes(int64_t batch, int n_contact, int n_cone, int max_iter, size_t* bytes) {
+  GQ_REQUIRE(bytes && batch >= 0 && n_contact > 0 && n_cone > 0, "fc_workspace_bytes: bad arguments");
+  const size_t nz = (size_t)n_contact * n_cone, B = (size_t)batch;
+  size_t qp = 0;
+  int rc = gq_boxqp_workspace_bytes(batch, (int)nz, max_iter, &qp);
+  if (rc) return rc;
+  *bytes = gq_al(B * 6 * nz * 4) + gq_al(B * nz * 4) * 4 + gq_al(B * 2 * nz * 4) * 3 + gq_al(B * 4) * 2 + qp + 512;
+  return GQ_OK;
+}
+
+struct GqFcWs {
+  float *F, *x, *lam, *slack, *Ftr, *dldx, *dx, *dlam, *val, *svd;
+  void* qp;
+  size_t qp_bytes;
+};
+static GqFcWs gq_fc_carve(void* base, size_t B, size_t nz, size_t total) {
+  GqFcWs w;
+  char* c = (char*)base;
+  size_t o = 0;
+  w.F = (float*)(c + o); o += gq_al(B * 6 * nz * 4);
+  w.x = (float*)(c + o); o += gq_al(B * nz * 4);
+  w.Ftr = (float*)(c + o); o += gq_al(B * nz * 4);
+  w.dldx = (float*)(c + o); o += gq_al(B * nz * 4);
+  w.dx = (float*)(c + o); o += gq_al(B * nz * 4);
+  w.lam = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
+  w.slack = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
+  w.dlam = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
+  w.val = (float*)(c + o); o += gq_al(B * 4);
+  w.svd = (float*)(c + o); o += gq_al(B * 4);
+  w.qp = (void*)(c + o);
+  w.qp_bytes = total > o ? total - o : 0;
+  return w;
+}
+
+// E_fc forward (energy_fnc of reference energy.py:35-42 for energy_type "graspqp").
+int gq_fc_forward(const float* contact_pts, const float* contact_normals, const float* cog, int64_t batch,
+                  int n_contact, int n_cone, float friction, float torque_weight, float max_limit, float svd_gain,
+                  float values_gain, float eps, int max_iter, float* e_fc, float* x_sum, int32_t* n_iter,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GQ_REQUIRE(contact_pts && contact_normals && cog && e_fc && workspace, "fc_forward: null pointer");
+  GQ_REQUIRE(batch > 0 && n_contact > 0 && n_cone > 0, "fc_forward: bad sizes");
+  const int nz = n_contact * n_cone;
+  size_t need = 0;
+  int rc = gq_fc_workspace_bytes(batch, n_contact, n_cone, max_iter, &need);
+  if (rc) return rc;
+  GQ_REQUIRE(workspace_bytes >= need, "fc_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+  GqFcWs w = gq_fc_carve(workspace, (size_t)batch, (size_t)nz, workspace_bytes);
+  const int64_t tot = batch * nz;
+  hipLaunchKernelGGL(gq_grasp_matrix_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, contact_pts,
+                     contact_normals, cog, (int)batch, n_contact, n_cone, friction, torque_weight, w.F);
+  GQ_LAUNCH_CHECK();
+  // bounds 1 <= x <= max_limit + 1, b = 0, ridge 1e-4 (span.py:348-349, qp_solver.py:101-112)
+  rc = gq_lsq_boxqp_forward(w.F, nullptr, nullptr, nullptr, 1.0f, max_limit + 1.0f, batch, 6, nz, 1e-4f, eps,
+                            max_iter, 3, w.x, w.lam, w.slack, nullptr, n_iter, w.qp, w.qp_bytes, stream);
+  if (rc) return rc;
+  GqFcArgs a{};
+  a.F = w.F;
+  a.x = w.x;
+  a.B = (int)batch;
+  a.n = n_contact;
+  a.k = n_cone;
+  a.svd_gain = svd_gain;
+  a.values_gain = values_gain;
+  a.eps_add = 1e-2f;
+  a.e_fc = e_fc;
+  a.val = w.val;
+  a.svd = w.svd;
+  a.Ftr = w.Ftr;
+  a.x_sum = x_sum;
+  hipLaunchKernelGGL(gq_fc_energy_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, st, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+// Gradient of E_fc wrt contact_pts for upstream grad_e (B,); must follow gq_fc_forward on the same workspace.
+int gq_fc_backward(const float* contact_pts, const float* contact_normals, const float* cog, const float* grad_e,
+                   int64_t batch, int n_contact, int n_cone, float friction, float torque_weight, float svd_gain,
+                   float values_gain, float* grad_contact_pts, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GQ_REQUIRE(contact_pts && contact_normals && cog && grad_e && grad_contact_pts && workspace, "fc_backward: null");
+  GQ_REQUIRE(batch > 0 && n_contact > 0 && n_cone > 0, "fc_backward: bad sizes");
+  const int nz = n_contact * n_cone;
+  GqFcWs w = gq_fc_carve(workspace, (size_t)batch, (size_t)nz, workspace_bytes);
+  const int64_t tot = batch * nz;
+  hipLaunchKernelGGL(gq_fc_dldx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, grad_e, w.svd, w.Ftr,
+                     (int)batch, nz, svd_gain, values_gain, w.dldx);
+  GQ_LAUNCH_CHECK();
+  int rc = gq_lsq_boxqp_backward(w.F, w.lam, w.slack, w.dldx, batch, 6, nz, 1e-4f, w.dx, w.dlam, stream);
+  if (rc) return rc;
+  GqFcBwdArgs a{};
+  a.F = w.F;
+  a.x = w.x;
+  a.dx = w.dx;
+  a.cpts = contact_pts;
+  a.cnrm = contact_normals;
+  a.cog = cog;
+  a.g_e = grad_e;
+  a.val = w.val;
+  a.svd = w.svd;
+  a.B = (int)batch;
+  a.n = n_contact;
+  a.k = n_cone;
+  a.mu = friction;
+  a.tw = torque_weight;
+  a.svd_gain = svd_gain;
+  a.values_gain = values_gain;
+  a.eps_add = 1e-2f;
+  a.g_cpts = grad_contact_pts;
+  hipLaunchKernelGGL(gq_fc_grad_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), (size_t)nz * 3 * sizeof(float), st, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+// expose intermediate results of the last gq_fc_forward on `workspace` (parity tests / SQPLsqSolver-level users)
+int gq_fc_peek(void* workspace, size_t workspace_bytes, int64_t batch, int n_contact, int n_cone, const float** F,
+               const float** x, const float** val, const float** svd) {
+  GQ_REQUIRE(workspace, "fc_peek: null");
+  GqFcWs w = gq_fc_carve(workspace, (size_t)batch, (size_t)n_contact * n_cone, workspace_bytes);
+  if (F) *F = w.F;
+  if (x) *x = w.x;
+  if (val) *val = w.val;
+  if (svd) *svd = w.svd;
+  return GQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,488 @@
+// Hand kinematics for the grasp loop: rot6d -> R, URDF tree FK, contact points / normals, penetration spheres,
+// and the analytic backward pass (geometric Jacobian via per-node wrench accumulation) that replaces autograd
+// through pytorch_kinematics (reference hand_model.py:762-766, 787-873, 1220-1267; utils/transforms.py:5-13).
+//
+// Work shape: one thread per grasp candidate (row).  Per row the work is ~2 kflop of strictly sequential 3x3
+// products down a 16-24 joint tree, i.e. latency- not throughput-bound; the per-row scratch (node transforms,
+// node wrenches) lives in a caller-provided workspace so nothing is dynamically indexed in registers.
+#include "common.h"
+
+struct gqHand {
+  int J, L, C, S, NG;
+  int32_t *node_parent, *node_type, *link_node, *cand_link, *sphere_link, *group_off;
+  float *node_pre, *node_axis, *link_offset, *cand_pos, *cand_nrm, *sphere, *jlo, *jhi;
+};
+
+// 3x4 row-major [R|t] helpers ------------------------------------------------------------------------------------
+struct GqT {
+  float m[12];
+};
+__device__ __forceinline__ GqT gq_t_identity() {
+  GqT t;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t.m[i] = (i == 0 || i == 5 || i == 10) ? 1.0f : 0.0f;
+  return t;
+}
+__device__ __forceinline__ GqT gq_t_load(const float* p) {
+  GqT t;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t.m[i] = p[i];
+  return t;
+}
+__device__ __forceinline__ void gq_t_store(float* p, const GqT& t) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) p[i] = t.m[i];
+}
+__device__ __forceinline__ GqT gq_t_mul(const GqT& a, const GqT& b) {
+  GqT c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = a.m[i * 4 + 0] * b.m[0 * 4 + j] + a.m[i * 4 + 1] * b.m[1 * 4 + j] + a.m[i * 4 + 2] * b.m[2 * 4 + j];
+      if (j == 3) v += a.m[i * 4 + 3];
+      c.m[i * 4 + j] = v;
+    }
+  }
+  return c;
+}
+__device__ __forceinline__ gq3 gq_t_rot(const GqT& t, gq3 v) {
+  return gq_mk(t.m[0] * v.x + t.m[1] * v.y + t.m[2] * v.z, t.m[4] * v.x + t.m[5] * v.y + t.m[6] * v.z,
+               t.m[8] * v.x + t.m[9] * v.y + t.m[10] * v.z);
+}
+__device__ __forceinline__ gq3 gq_t_pos(const GqT& t) { return gq_mk(t.m[3], t.m[7], t.m[11]); }
+__device__ __forceinline__ gq3 gq_t_apply(const GqT& t, gq3 v) { return gq_t_rot(t, v) + gq_t_pos(t); }
+
+// joint motion: Rodrigues rotation about a unit axis, or translation along it
+__device__ __forceinline__ GqT gq_joint_motion(int type, gq3 a, float q) {
+  GqT t = gq_t_identity();
+  if (type == 1) {
+    float s, c;
+    sincosf(q, &s, &c);
+    const float v = 1.0f - c;
+    t.m[0] = c + v * a.x * a.x;
+    t.m[1] = v * a.x * a.y - s * a.z;
+    t.m[2] = v * a.x * a.z + s * a.y;
+    t.m[4] = v * a.y * a.x + s * a.z;
+    t.m[5] = c + v * a.y * a.y;
+    t.m[6] = v * a.y * a.z - s * a.x;
+    t.m[8] = v * a.z * a.x - s * a.y;
+    t.m[9] = v * a.z * a.y + s * a.x;
+    t.m[10] = c + v * a.z * a.z;
+  } else {
+    t.m[3] = a.x * q;
+    t.m[7] = a.y * q;
+    t.m[11] = a.z * q;
+  }
+  return t;
+}
+
+// rot6d (first two columns of R) -> R row-major; roma.special_gramschmidt
+__device__ __forceinline__ void gq_rot6d(const float* six, float* R) {
+  gq3 a = gq_mk(six[0], six[1], six[2]), b = gq_mk(six[3], six[4], six[5]);
+  const gq3 x = (1.0f / sqrtf(gq_dot(a, a))) * a;
+  gq3 y = b - gq_dot(x, b) * x;
+  y = (1.0f / sqrtf(gq_dot(y, y))) * y;
+  const gq3 z = gq_cross(x, y);
+  R[0] = x.x; R[1] = y.x; R[2] = z.x;
+  R[3] = x.y; R[4] = y.y; R[5] = z.y;
+  R[6] = x.z; R[7] = y.z; R[8] = z.z;
+}
+
+struct GqFkArgs {
+  gqHand h;
+  const float* hand_pose;  // (B, D)  D = 9 + J
+  const int64_t* idx;      // (B, n)
+  int B, n, D;
+  float* Rg;        // (B, 9)
+  float* link_T;    // (B, L, 12)
+  float* node_W;    // (B, J, 12) workspace / saved for backward
+  float* cpts;      // (B, n, 3)
+  float* cnrm;      // (B, n, 3)
+  float* spheres;   // (B, S, 3) or null
+};
+
+__global__ __launch_bounds__(64) void gq_fk_forward_kernel(GqFkArgs g) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.B) return;
+  const gqHand& h = g.h;
+  const float* hp = g.hand_pose + (size_t)row * g.D;
+  float R[9];
+  gq_rot6d(hp + 3, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) g.Rg[(size_t)row * 9 + i] = R[i];
+  const gq3 tg = gq_mk(hp[0], hp[1], hp[2]);
+  float* W = g.node_W + (size_t)row * h.J * 12;
+  for (int j = 0; j < h.J; ++j) {
+    const int p = h.node_parent[j];
+    const GqT pre = gq_t_load(h.node_pre + j * 12);
+    const gq3 ax = gq_mk(h.node_axis[j * 3], h.node_axis[j * 3 + 1], h.node_axis[j * 3 + 2]);
+    GqT A = gq_t_mul(pre, gq_joint_motion(h.node_type[j], ax, hp[9 + j]));
+    if (p >= 0) A = gq_t_mul(gq_t_load(W + p * 12), A);
+    gq_t_store(W + j * 12, A);
+  }
+  float* LT = g.link_T + (size_t)row * h.L * 12;
+  for (int l = 0; l < h.L; ++l) {
+    const int nd = h.link_node[l];
+    GqT T = gq_t_load(h.link_offset + l * 12);
+    if (nd >= 0) T = gq_t_mul(gq_t_load(W + nd * 12), T);
+    gq_t_store(LT + l * 12, T);
+  }
+  for (int c = 0; c < g.n; ++c) {
+    const int ci = (int)g.idx[(size_t)row * g.n + c];
+    const int l = h.cand_link[ci];
+    const GqT T = gq_t_load(LT + l * 12);
+    const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
+    const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
+    const gq3 pw = gq_mv(R, ph) + tg;
+    const gq3 nw = gq_mv(R, nh);
+    float* o = g.cpts + ((size_t)row * g.n + c) * 3;
+    o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+    o = g.cnrm + ((size_t)row * g.n + c) * 3;
+    o[0] = nw.x; o[1] = nw.y; o[2] = nw.z;
+  }
+  if (g.spheres) {
+    for (int s = 0; s < h.S; ++s) {
+      const GqT T = gq_t_load(LT + h.sphere_link[s] * 12);
+      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[s * 4], h.sphere[s * 4 + 1], h.sphere[s * 4 + 2]));
+      const gq3 pw = gq_mv(R, ph) + tg;
+      float* o = g.spheres + ((size_t)row * h.S + s) * 3;
+      o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+    }
+  }
+}
+
+struct GqFkBwdArgs {
+  gqHand h;
+  const float* hand_pose;
+  const int64_t* idx;
+  const float* Rg;
+  const float* link_T;
+  const float* node_W;
+  const float* g_cpts;     // (B,n,3) or null
+  const float* g_cnrm;     // (B,n,3) or null
+  const float* g_spheres;  // (B,S,3) or null
+  const float* g_wrench;   // (B,L,6) hand-frame link wrench (f, m about hand origin) or null
+  const float* g_Rt;       // (B,12): [gsum(3), K(9)] from the penetration query or null
+  const float* g_theta;    // (B,J) direct joint-angle gradient (E_joints) or null
+  const float* g_R;        // (B,9) direct gradient on the global rotation matrix or null
+  int B, n, D;
+  float* node_F;     // (B, J, 6) workspace
+  float* grad_pose;  // (B, D)
+};
+
+__device__ __forceinline__ void gq_add6(float* a, gq3 f, gq3 m) {
+  a[0] += f.x; a[1] += f.y; a[2] += f.z;
+  a[3] += m.x; a[4] += m.y; a[5] += m.z;
+}
+
+__global__ __launch_bounds__(64) void gq_fk_backward_kernel(GqFkBwdArgs g) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= g.B) return;
+  const gqHand& h = g.h;
+  const float* hp = g.hand_pose + (size_t)row * g.D;
+  const float* R = g.Rg + (size_t)row * 9;
+  const float* LT = g.link_T + (size_t)row * h.L * 12;
+  const float* W = g.node_W + (size_t)row * h.J * 12;
+  float* NF = g.node_F + (size_t)row * h.J * 6;
+  for (int i = 0; i < h.J * 6; ++i) NF[i] = 0.0f;
+  gq3 gt = gq_mk(0, 0, 0);
+  float gR[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) gR[i] = g.g_R ? g.g_R[(size_t)row * 9 + i] : 0.0f;
+
+  if (g.g_Rt) {  // grad_t = -R gsum ; grad_R = R K
+    const float* e = g.g_Rt + (size_t)row * 12;
+    gt = gt - gq_mv(R, gq_mk(e[0], e[1], e[2]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        gR[i * 3 + j] += R[i * 3 + 0] * e[3 + 0 * 3 + j] + R[i * 3 + 1] * e[3 + 1 * 3 + j] + R[i * 3 + 2] * e[3 + 2 * 3 + j];
+  }
+  if (g.g_wrench) {
+    for (int l = 0; l < h.L; ++l) {
+      const int nd = h.link_node[l];
+      if (nd < 0) continue;
+      const float* w = g.g_wrench + ((size_t)row * h.L + l) * 6;
+      gq_add6(NF + nd * 6, gq_mk(w[0], w[1], w[2]), gq_mk(w[3], w[4], w[5]));
+    }
+  }
+  if (g.g_cpts || g.g_cnrm) {
+    for (int c = 0; c < g.n; ++c) {
+      const int ci = (int)g.idx[(size_t)row * g.n + c];
+      const int l = h.cand_link[ci];
+      const GqT T = gq_t_load(LT + l * 12);
+      const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
+      const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
+      gq3 f = gq_mk(0, 0, 0), m = gq_mk(0, 0, 0);
+      if (g.g_cpts) {
+        const float* q = g.g_cpts + ((size_t)row * g.n + c) * 3;
+        const gq3 gp = gq_mk(q[0], q[1], q[2]);
+        gt = gt + gp;
+        gR[0] += gp.x * ph.x; gR[1] += gp.x * ph.y; gR[2] += gp.x * ph.z;
+        gR[3] += gp.y * ph.x; gR[4] += gp.y * ph.y; gR[5] += gp.y * ph.z;
+        gR[6] += gp.z * ph.x; gR[7] += gp.z * ph.y; gR[8] += gp.z * ph.z;
+        const gq3 gph = gq_mtv(R, gp);
+        f = f + gph;
+        m = m + gq_cross(ph, gph);
+      }
+      if (g.g_cnrm) {
+        const float* q = g.g_cnrm + ((size_t)row * g.n + c) * 3;
+        const gq3 gn = gq_mk(q[0], q[1], q[2]);
+        gR[0] += gn.x * nh.x; gR[1] += gn.x * nh.y; gR[2] += gn.x * nh.z;
+        gR[3] += gn.y * nh.x; gR[4] += gn.y * nh.y; gR[5] += gn.y * nh.z;
+        gR[6] += gn.z * nh.x; gR[7] += gn.z * nh.y; gR[8] += gn.z * nh.z;
+        m = m + gq_cross(nh, gq_mtv(R, gn));
+      }
+      const int nd = h.link_node[l];
+      if (nd >= 0) gq_add6(NF + nd * 6, f, m);
+    }
+  }
+  if (g.g_spheres) {
+    for (int s = 0; s < h.S; ++s) {
+      const float* q = g.g_spheres + ((size_t)row * h.S + s) * 3;
+      const gq3 gp = gq_mk(q[0], q[1], q[2]);
+      if (gp.x == 0.0f && gp.y == 0.0f && gp.z == 0.0f) continue;
+      const int l = h.sphere_link[s];
+      const GqT T = gq_t_load(LT + l * 12);
+      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[s * 4], h.sphere[s * 4 + 1], h.sphere[s * 4 + 2]));
+      gt = gt + gp;
+      gR[0] += gp.x * ph.x; gR[1] += gp.x * ph.y; gR[2] += gp.x * ph.z;
+      gR[3] += gp.y * ph.x; gR[4] += gp.y * ph.y; gR[5] += gp.y * ph.z;
+      gR[6] += gp.z * ph.x; gR[7] += gp.z * ph.y; gR[8] += gp.z * ph.z;
+      const gq3 gph = gq_mtv(R, gp);
+      const int nd = h.link_node[l];
+      if (nd >= 0) gq_add6(NF + nd * 6, gph, gq_cross(ph, gph));
+    }
+  }
+  float* go = g.grad_pose + (size_t)row * g.D;
+  // joints, leaves to root: d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
+  for (int j = h.J - 1; j >= 0; --j) {
+    const float* w = NF + j * 6;
+    const gq3 f = gq_mk(w[0], w[1], w[2]), m = gq_mk(w[3], w[4], w[5]);
+    const GqT Wj = gq_t_load(W + j * 12);
+    const gq3 aw = gq_t_rot(Wj, gq_mk(h.node_axis[j * 3], h.node_axis[j * 3 + 1], h.node_axis[j * 3 + 2]));
+    const gq3 o = gq_t_pos(Wj);
+    float gth = (h.node_type[j] == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
+    if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + j];
+    go[9 + j] = gth;
+    const int p = h.node_parent[j];
+    if (p >= 0) gq_add6(NF + p * 6, f, m);
+  }
+  go[0] = gt.x; go[1] = gt.y; go[2] = gt.z;
+  // Gram-Schmidt backward: columns of gR are the gradients of x, y, z
+  const gq3 a = gq_mk(hp[3], hp[4], hp[5]), b = gq_mk(hp[6], hp[7], hp[8]);
+  const float na = sqrtf(gq_dot(a, a));
+  const gq3 x = (1.0f / na) * a;
+  const gq3 yp = b - gq_dot(x, b) * x;
+  const float ny = sqrtf(gq_dot(yp, yp));
+  const gq3 y = (1.0f / ny) * yp;
+  gq3 gx = gq_mk(gR[0], gR[3], gR[6]), gy = gq_mk(gR[1], gR[4], gR[7]);
+  const gq3 gz = gq_mk(gR[2], gR[5], gR[8]);
+  gx = gx + gq_cross(y, gz);
+  gy = gy + gq_cross(gz, x);
+  const gq3 gyp = (1.0f / ny) * (gy - gq_dot(gy, y) * y);
+  const gq3 gb = gyp - gq_dot(gyp, x) * x;
+  gx = gx - gq_dot(x, b) * gyp - gq_dot(gyp, x) * b;
+  const gq3 ga = (1.0f / na) * (gx - gq_dot(gx, x) * x);
+  go[3] = ga.x; go[4] = ga.y; go[5] = ga.z;
+  go[6] = gb.x; go[7] = gb.y; go[8] = gb.z;
+}
+
+// ---- self penetration (hand_model.py:989-1040) ----------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* __restrict__ centers, int B,
+                                                         float* __restrict__ e_spen, float* __restrict__ g_centers) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B) return;
+  const float* c = centers + (size_t)row * h.S * 3;
+  float* gc = g_centers + (size_t)row * h.S * 3;
+  for (int i = 0; i < h.S * 3; ++i) gc[i] = 0.0f;
+  float e = 0.0f;
+  for (int gi = 0; gi + 1 < h.NG; ++gi) {
+    const int a0 = h.group_off[gi], a1 = h.group_off[gi + 1];
+    float best = GQ_INF_F;
+    int ba = -1, bb = -1;
+    for (int a = a0; a < a1; ++a) {
+      const gq3 pa = gq_mk(c[a * 3], c[a * 3 + 1], c[a * 3 + 2]);
+      const float ra = h.sphere[a * 4 + 3];
+      for (int b = a1; b < h.S; ++b) {
+        const gq3 d = gq_mk(pa.x - c[b * 3] + 1e-13f, pa.y - c[b * 3 + 1] + 1e-13f, pa.z - c[b * 3 + 2] + 1e-13f);
+        const float pen = sqrtf(gq_dot(d, d)) - (ra + h.sphere[b * 4 + 3]);
+        if (pen < best) {
+          best = pen;
+          ba = a;
+          bb = b;
+        }
+      }
+    }
+    if (best < 0.0f && ba >= 0) {
+      e -= best;
+      const gq3 d = gq_mk(c[ba * 3] - c[bb * 3] + 1e-13f, c[ba * 3 + 1] - c[bb * 3 + 1] + 1e-13f,
+                          c[ba * 3 + 2] - c[bb * 3 + 2] + 1e-13f);
+      const float inv = 1.0f / sqrtf(gq_dot(d, d));
+      // E += -|a-b| + ... : dE/da = -(a-b)/|a-b|, dE/db = +(a-b)/|a-b|
+      gc[ba * 3] -= d.x * inv; gc[ba * 3 + 1] -= d.y * inv; gc[ba * 3 + 2] -= d.z * inv;
+      gc[bb * 3] += d.x * inv; gc[bb * 3 + 1] += d.y * inv; gc[bb * 3 + 2] += d.z * inv;
+    }
+  }
+  e_spen[row] = e;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+struct gqHandDesc {
+  int32_t n_dofs, n_links, n_cand, n_spheres;
+  const int32_t* node_parent;
+  const int32_t* node_type;
+  const float* node_pre;     // (J, 12)
+  const float* node_axis;    // (J, 3)
+  const int32_t* link_node;  // (L)
+  const float* link_offset;  // (L, 12)
+  const float* cand_pos;     // (C, 3)
+  const float* cand_nrm;     // (C, 3)
+  const int32_t* cand_link;  // (C)
+  const float* sphere;       // (S, 4)
+  const int32_t* sphere_link;  // (S), non-decreasing
+  const float* joints_lower;   // (J)
+  const float* joints_upper;   // (J)
+};
+
+template <typename T>
+static int gq_upload(T** dst, const T* src, size_t n) {
+  *dst = nullptr;
+  if (n == 0) return GQ_OK;
+  GQ_CHECK_HIP(hipMalloc((void**)dst, n * sizeof(T)));
+  GQ_CHECK_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return GQ_OK;
+}
+
+extern "C" {
+
+int gq_hand_create(const gqHandDesc* d, gqHand** out) {
+  GQ_REQUIRE(d && out, "hand_create: null");
+  GQ_REQUIRE(d->n_dofs > 0 && d->n_dofs <= 64 && d->n_links > 0 && d->n_cand >= 0 && d->n_spheres >= 0,
+             "hand_create: bad sizes J=%d L=%d C=%d S=%d", d->n_dofs, d->n_links, d->n_cand, d->n_spheres);
+  for (int j = 0; j < d->n_dofs; ++j)
+    GQ_REQUIRE(d->node_parent[j] < j && d->node_parent[j] >= -1, "hand_create: node_parent must be topologically sorted");
+  for (int l = 0; l < d->n_links; ++l)
+    GQ_REQUIRE(d->link_node[l] >= -1 && d->link_node[l] < d->n_dofs, "hand_create: link_node out of range");
+  for (int c = 0; c < d->n_cand; ++c)
+    GQ_REQUIRE(d->cand_link[c] >= 0 && d->cand_link[c] < d->n_links, "hand_create: cand_link out of range");
+  for (int s = 0; s < d->n_spheres; ++s) {
+    GQ_REQUIRE(d->sphere_link[s] >= 0 && d->sphere_link[s] < d->n_links, "hand_create: sphere_link out of range");
+    GQ_REQUIRE(s == 0 || d->sphere_link[s] >= d->sphere_link[s - 1], "hand_create: sphere_link must be sorted");
+  }
+  gqHand* h = new gqHand();
+  h->J = d->n_dofs;
+  h->L = d->n_links;
+  h->C = d->n_cand;
+  h->S = d->n_spheres;
+  int32_t groups[258];
+  int ng = 0;
+  for (int s = 0; s < d->n_spheres && ng < 256; ++s)
+    if (s == 0 || d->sphere_link[s] != d->sphere_link[s - 1]) groups[ng++] = s;
+  groups[ng] = d->n_spheres;
+  h->NG = ng;
+  int rc = 0;
+  rc |= gq_upload(&h->node_parent, d->node_parent, h->J);
+  rc |= gq_upload(&h->node_type, d->node_type, h->J);
+  rc |= gq_upload(&h->node_pre, d->node_pre, (size_t)h->J * 12);
+  rc |= gq_upload(&h->node_axis, d->node_axis, (size_t)h->J * 3);
+  rc |= gq_upload(&h->link_node, d->link_node, h->L);
+  rc |= gq_upload(&h->link_offset, d->link_offset, (size_t)h->L * 12);
+  rc |= gq_upload(&h->cand_pos, d->cand_pos, (size_t)h->C * 3);
+  rc |= gq_upload(&h->cand_nrm, d->cand_nrm, (size_t)h->C * 3);
+  rc |= gq_upload(&h->cand_link, d->cand_link, h->C);
+  rc |= gq_upload(&h->sphere, d->sphere, (size_t)h->S * 4);
+  rc |= gq_upload(&h->sphere_link, d->sphere_link, h->S);
+  rc |= gq_upload(&h->jlo, d->joints_lower, h->J);
+  rc |= gq_upload(&h->jhi, d->joints_upper, h->J);
+  rc |= gq_upload(&h->group_off, (const int32_t*)groups, (size_t)ng + 1);
+  if (rc) return GQ_ERR_HIP;
+  *out = h;
+  return GQ_OK;
+}
+
+int gq_hand_destroy(gqHand* h) {
+  if (!h) return GQ_OK;
+  void* p[] = {h->node_parent, h->node_type, h->node_pre, h->node_axis, h->link_node, h->link_offset, h->cand_pos,
+               h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off};
+  for (void* q : p)
+    if (q) hipFree(q);
+  delete h;
+  return GQ_OK;
+}
+
+// workspace: node_W (B,J,12) floats [kept for backward] + node_F (B,J,6) floats
+int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes) {
+  GQ_REQUIRE(h && bytes && batch >= 0, "fk_workspace_bytes: bad arguments");
+  *bytes = (size_t)batch * h->J * 18 * sizeof(float) + 256;
+  return GQ_OK;
+}
+
+int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
+                  float* Rg, float* link_T, float* contact_points, float* contact_normals, float* sphere_centers,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  GQ_REQUIRE(h && hand_pose && Rg && link_T && workspace, "fk_forward: null pointer");
+  GQ_REQUIRE(batch > 0 && n_contact >= 0, "fk_forward: bad sizes");
+  GQ_REQUIRE(n_contact == 0 || (contact_idx && contact_points && contact_normals), "fk_forward: null contact buffers");
+  GQ_REQUIRE(workspace_bytes >= (size_t)batch * h->J * 18 * sizeof(float), "fk_forward: workspace too small");
+  GqFkArgs a{};
+  a.h = *h;
+  a.hand_pose = hand_pose;
+  a.idx = contact_idx;
+  a.B = (int)batch;
+  a.n = n_contact;
+  a.D = 9 + h->J;
+  a.Rg = Rg;
+  a.link_T = link_T;
+  a.node_W = (float*)workspace;
+  a.cpts = contact_points;
+  a.cnrm = contact_normals;
+  a.spheres = sphere_centers;
+  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
+                   const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
+                   const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
+                   const float* g_R, float* grad_pose, void* workspace, size_t workspace_bytes, void* stream) {
+  GQ_REQUIRE(h && hand_pose && Rg && link_T && grad_pose && workspace, "fk_backward: null pointer");
+  GQ_REQUIRE(batch > 0 && n_contact >= 0, "fk_backward: bad sizes");
+  GQ_REQUIRE(workspace_bytes >= (size_t)batch * h->J * 18 * sizeof(float), "fk_backward: workspace too small");
+  GqFkBwdArgs a{};
+  a.h = *h;
+  a.hand_pose = hand_pose;
+  a.idx = contact_idx;
+  a.Rg = Rg;
+  a.link_T = link_T;
+  a.node_W = (const float*)workspace;
+  a.g_cpts = g_contact_points;
+  a.g_cnrm = g_contact_normals;
+  a.g_spheres = g_sphere_centers;
+  a.g_wrench = g_link_wrench;
+  a.g_Rt = g_Rt;
+  a.g_theta = g_theta;
+  a.g_R = g_R;
+  a.B = (int)batch;
+  a.n = (g_contact_points || g_contact_normals) ? n_contact : 0;
+  a.D = 9 + h->J;
+  a.node_F = (float*)workspace + (size_t)batch * h->J * 12;
+  a.grad_pose = grad_pose;
+  hipLaunchKernelGGL(gq_fk_backward_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+int gq_self_pen_forward(const gqHand* h, const float* sphere_centers, int64_t batch, float* e_spen, float* g_centers,
+                        void* stream) {
+  GQ_REQUIRE(h && sphere_centers && e_spen && g_centers && batch > 0, "self_pen_forward: bad arguments");
+  hipLaunchKernelGGL(gq_self_pen_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *h,
+                     sphere_centers, (int)batch, e_spen, g_centers);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+}  // extern "C"

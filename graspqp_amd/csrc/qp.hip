@@ -1,0 +1,250 @@
+// Batched box-constrained QP (force-closure QP of GraspQP) for gfx950: one problem per wavefront.
+//
+// Forward = qpth-style primal-dual interior point with batch-global stopping, split in three launches
+// so that no wave ever waits for another:
+//   gq_qp_iter_kernel    every row runs all max_iter iterations, recording resid/mu per iteration and a
+//                        snapshot (x, lam, slack) at each iteration that improves the row's best residual
+//   gq_qp_stop_kernel    one block replays qpth's batch-global rule (notImproved == 3 | max best < eps |
+//                        min mu > 1e32) on the (B, max_iter) residual table -> stop iteration k*
+//   gq_qp_select_kernel  each row returns its best snapshot among iterations 0..k*
+// Backward = one more reduced-KKT solve at the returned point (qpth QPFunction.backward).
+#include "qp_kernels.h"
+
+// ---- batch-global stopping rule (single block) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void gq_qp_stop_kernel(const float* __restrict__ resid, const float* __restrict__ mu,
+                                                         int B, int max_iter, float eps, int not_improved_lim,
+                                                         float* __restrict__ runmin, int* __restrict__ kstar) {
+  __shared__ int s_any;
+  __shared__ float s_red[256];
+  __shared__ float s_red2[256];
+  __shared__ int s_stop;
+  const int tid = threadIdx.x;
+  int not_improved = 0;
+  int stop_at = max_iter - 1;
+  for (int it = 0; it < max_iter; ++it) {
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    float mx = -GQ_INF, mn = GQ_INF;
+    int any = 0;
+    for (int r = tid; r < B; r += 256) {
+      const float rs = resid[(size_t)r * max_iter + it];
+      float bst;
+      if (it == 0) {
+        bst = rs;
+      } else {
+        bst = runmin[r];
+        if (rs < bst) {
+          bst = rs;
+          any = 1;
+        }
+      }
+      runmin[r] = bst;
+      mx = gq_nanmax(mx, bst);
+      mn = gq_nanmin(mn, mu[(size_t)r * max_iter + it]);
+    }
+    if (any) atomicOr(&s_any, 1);
+    s_red[tid] = mx;
+    s_red2[tid] = mn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        s_red[tid] = gq_nanmax(s_red[tid], s_red[tid + o]);
+        s_red2[tid] = gq_nanmin(s_red2[tid], s_red2[tid + o]);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (it == 0) not_improved = 0;
+      else not_improved = s_any ? 0 : not_improved + 1;
+      s_stop = (not_improved == not_improved_lim) || (s_red[0] < eps) || (s_red2[0] > 1e32f);
+    }
+    __syncthreads();
+    if (s_stop) {
+      stop_at = it;
+      break;
+    }
+  }
+  if (tid == 0) {
+    kstar[0] = stop_at;      // last iteration whose record counts
+    kstar[1] = stop_at + 1;  // qpth-style iteration count
+  }
+}
+
+__global__ __launch_bounds__(GQ_WAVE) void gq_qp_select_kernel(const float* __restrict__ resid,
+                                                               const float* __restrict__ snap,
+                                                               const int* __restrict__ kstar, int B, int nz,
+                                                               int max_iter, float* __restrict__ x,
+                                                               float* __restrict__ lam, float* __restrict__ slack,
+                                                               int* __restrict__ best_iter) {
+  const int row = blockIdx.x;
+  const int lane = gq_lane();
+  const int ks = kstar[0];
+  float bst = 0.0f;
+  int bi = 0;
+  for (int it = 0; it <= ks; ++it) {
+    const float rs = resid[(size_t)row * max_iter + it];
+    if (it == 0 || rs < bst) {
+      bst = rs;
+      bi = it;
+    }
+  }
+  if (lane < nz) {
+    const float* s = snap + (((size_t)row * max_iter + bi) * 5) * nz + lane;
+    x[(size_t)row * nz + lane] = s[0];
+    lam[(size_t)row * 2 * nz + lane] = s[nz];
+    lam[(size_t)row * 2 * nz + nz + lane] = s[2 * nz];
+    slack[(size_t)row * 2 * nz + lane] = s[3 * nz];
+    slack[(size_t)row * 2 * nz + nz + lane] = s[4 * nz];
+  }
+  if (lane == 0 && best_iter) best_iter[row] = bi;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static size_t gq_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct GqQpWs {
+  float *resid, *mu, *snap, *runmin;
+  int* kstar;
+  size_t total;
+};
+static GqQpWs gq_qp_carve(void* base, int B, int nz, int max_iter) {
+  GqQpWs w;
+  size_t off = 0;
+  char* c = (char*)base;
+  w.resid = (float*)(c + off);
+  off += gq_align((size_t)B * max_iter * 4);
+  w.mu = (float*)(c + off);
+  off += gq_align((size_t)B * max_iter * 4);
+  w.snap = (float*)(c + off);
+  off += gq_align((size_t)B * max_iter * 5 * nz * 4);
+  w.runmin = (float*)(c + off);
+  off += gq_align((size_t)B * 4);
+  w.kstar = (int*)(c + off);
+  off += 256;
+  w.total = off;
+  return w;
+}
+
+static int gq_launch_iter(const GqQpArgs& a, int mode, hipStream_t st) {
+  if (a.nz <= 16) return gq_qp_launch_iter_16(a, mode, st);
+  if (a.nz <= 32) return gq_qp_launch_iter_32(a, mode, st);
+  if (a.nz <= 48) return gq_qp_launch_iter_48(a, mode, st);
+  return gq_qp_launch_iter_64(a, mode, st);
+}
+static int gq_launch_bwd(const GqQpBwdArgs& a, int mode, hipStream_t st) {
+  if (a.nz <= 16) return gq_qp_launch_bwd_16(a, mode, st);
+  if (a.nz <= 32) return gq_qp_launch_bwd_32(a, mode, st);
+  if (a.nz <= 48) return gq_qp_launch_bwd_48(a, mode, st);
+  return gq_qp_launch_bwd_64(a, mode, st);
+}
+
+static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, float* x, float* lam, float* slack,
+                                int* best_iter, int* n_iter, void* ws, size_t ws_bytes, hipStream_t st, int mode) {
+  GQ_REQUIRE(a.B > 0 && a.nz > 0, "boxqp: empty batch (B=%d nz=%d)", a.B, a.nz);
+  GQ_REQUIRE(a.nz <= 64, "boxqp: nz=%d > 64 is not supported by this build (one row per lane)", a.nz);
+  GQ_REQUIRE(a.max_iter >= 1 && a.max_iter <= 64, "boxqp: max_iter=%d out of range", a.max_iter);
+  GQ_REQUIRE(mode == 1 || (a.m >= 1 && a.m <= 8), "boxqp: m=%d must be in [1,8]", a.m);
+  GQ_REQUIRE(x && lam && slack && ws, "boxqp: null output/workspace pointer");
+  GqQpWs w = gq_qp_carve(ws, a.B, a.nz, a.max_iter);
+  GQ_REQUIRE(ws_bytes >= w.total, "boxqp: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  a.resid = w.resid;
+  a.mu = w.mu;
+  a.snap = w.snap;
+  int rc = gq_launch_iter(a, mode, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
+                     not_improved_lim, w.runmin, w.kstar);
+  GQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gq_qp_select_kernel, dim3(a.B), dim3(GQ_WAVE), 0, st, w.resid, w.snap, w.kstar, a.B, a.nz,
+                     a.max_iter, x, lam, slack, best_iter);
+  GQ_LAUNCH_CHECK();
+  if (n_iter) GQ_CHECK_HIP(hipMemcpyAsync(n_iter, w.kstar + 1, sizeof(int), hipMemcpyDeviceToDevice, st));
+  return GQ_OK;
+}
+
+extern "C" {
+
+int gq_boxqp_workspace_bytes(int64_t batch, int nz, int max_iter, size_t* bytes) {
+  GQ_REQUIRE(bytes != nullptr && batch >= 0 && nz > 0 && max_iter > 0, "boxqp_workspace_bytes: bad arguments");
+  *bytes = gq_qp_carve(nullptr, (int)batch, nz, max_iter).total;
+  return GQ_OK;
+}
+
+int gq_lsq_boxqp_forward(const float* A, const float* b, const float* lower, const float* upper, float lower_s,
+                         float upper_s, int64_t batch, int m, int nz, float ridge, float eps, int max_iter,
+                         int not_improved_lim, float* x, float* lam, float* slack, int32_t* best_iter,
+                         int32_t* n_iter, void* workspace, size_t workspace_bytes, void* stream) {
+  GQ_REQUIRE(A != nullptr, "lsq_boxqp_forward: A is null");
+  GqQpArgs a{};
+  a.A = A;
+  a.b = b;
+  a.lower = lower;
+  a.upper = upper;
+  a.lower_s = lower_s;
+  a.upper_s = upper_s;
+  a.ridge = ridge;
+  a.B = (int)batch;
+  a.m = m;
+  a.nz = nz;
+  a.max_iter = max_iter;
+  return gq_qp_forward_common(a, eps, not_improved_lim, x, lam, slack, best_iter, n_iter, workspace, workspace_bytes,
+                              (hipStream_t)stream, 0);
+}
+
+int gq_boxqp_forward(const float* Q, const float* p, const float* lower, const float* upper, float lower_s,
+                     float upper_s, int64_t batch, int nz, float eps, int max_iter, int not_improved_lim, float* x,
+                     float* lam, float* slack, int32_t* best_iter, int32_t* n_iter, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  GQ_REQUIRE(Q != nullptr, "boxqp_forward: Q is null");
+  GqQpArgs a{};
+  a.Q = Q;
+  a.p = p;
+  a.lower = lower;
+  a.upper = upper;
+  a.lower_s = lower_s;
+  a.upper_s = upper_s;
+  a.B = (int)batch;
+  a.m = 0;
+  a.nz = nz;
+  a.max_iter = max_iter;
+  return gq_qp_forward_common(a, eps, not_improved_lim, x, lam, slack, best_iter, n_iter, workspace, workspace_bytes,
+                              (hipStream_t)stream, 1);
+}
+
+int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, const float* grad_x, int64_t batch,
+                          int m, int nz, float ridge, float* dx, float* dlam, void* stream) {
+  GQ_REQUIRE(A && lam && slack && grad_x && dx && dlam, "lsq_boxqp_backward: null pointer");
+  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 64 && m >= 1 && m <= 8, "lsq_boxqp_backward: bad sizes B=%lld m=%d nz=%d",
+             (long long)batch, m, nz);
+  GqQpBwdArgs a{};
+  a.A = A;
+  a.lam = lam;
+  a.slack = slack;
+  a.grad_x = grad_x;
+  a.ridge = ridge;
+  a.B = (int)batch;
+  a.m = m;
+  a.nz = nz;
+  a.dx = dx;
+  a.dlam = dlam;
+  return gq_launch_bwd(a, 0, (hipStream_t)stream);
+}
+
+int gq_boxqp_backward(const float* Q, const float* lam, const float* slack, const float* grad_x, int64_t batch, int nz,
+                      float* dx, float* dlam, void* stream) {
+  GQ_REQUIRE(Q && lam && slack && grad_x && dx && dlam, "boxqp_backward: null pointer");
+  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 64, "boxqp_backward: bad sizes B=%lld nz=%d", (long long)batch, nz);
+  GqQpBwdArgs a{};
+  a.Q = Q;
+  a.lam = lam;
+  a.slack = slack;
+  a.grad_x = grad_x;
+  a.B = (int)batch;
+  a.m = 0;
+  a.nz = nz;
+  a.dx = dx;
+  a.dlam = dlam;
+  return gq_launch_bwd(a, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+// NZ = 16 instantiation of the box-QP kernels.
+#include "qp_kernels.h"
+GQ_DEFINE_QP_NZ(16)

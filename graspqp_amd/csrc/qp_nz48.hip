@@ -1,0 +1,3 @@
+// NZ = 48 instantiation of the box-QP kernels.
+#include "qp_kernels.h"
+GQ_DEFINE_QP_NZ(48)

@@ -1,0 +1,3 @@
+// NZ = 64 instantiation of the box-QP kernels.
+#include "qp_kernels.h"
+GQ_DEFINE_QP_NZ(64)

@@ -1,0 +1,126 @@
+// Point-triangle machinery shared by the SDF kernels.
+//
+// A mesh is kept on the device as an array of 64-byte face records precomputed once per mesh, so that the inner
+// loop needs no per-lane division and no per-lane edge vectors:
+//   [0..2] a       [3]  1/|ab|^2
+//   [4..6] ab      [7]  1/|ac|^2
+//   [8..10] ac     [11] 1/|bc|^2
+//   [12] |ac|^2/nn [13] (ab.ac)/nn [14] |ab|^2/nn   (nn = |ab x ac|^2; NaN for degenerate faces -> edge path)
+//   [15] |ab|^2 - ab.ac
+// Squared distance = plane-projection distance when the projection's barycentrics are all >= 0, else the minimum
+// over the three clamped edge projections -- exact closest point on a triangle (same result as the region
+// classification in the oracle, oracle/ref_cpu/sdf.py, up to fp32 round-off).
+#pragma once
+#include "common.h"
+
+struct GqFace {  // 16 floats
+  float4 r0, r1, r2, r3;
+};
+
+__device__ __forceinline__ float gq_sat(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+
+// squared distance from d = p - a to the triangle described by `f`
+__device__ __forceinline__ float gq_tri_dist2(const GqFace& f, gq3 d) {
+  const gq3 ab = gq_mk(f.r1.x, f.r1.y, f.r1.z), ac = gq_mk(f.r2.x, f.r2.y, f.r2.z);
+  const float d1 = gq_dot(ab, d), d2 = gq_dot(ac, d);
+  const float v = f.r3.x * d1 - f.r3.y * d2;
+  const float w = f.r3.z * d2 - f.r3.y * d1;
+  const float u = 1.0f - v - w;
+  const bool inside = fminf(fminf(v, w), u) >= 0.0f;  // false for NaN (degenerate face)
+  const gq3 rp = d - v * ab - w * ac;
+  const float dp = gq_dot(rp, rp);
+  const float t1 = gq_sat(d1 * f.r0.w);
+  const gq3 r1 = d - t1 * ab;
+  const float e1 = gq_dot(r1, r1);
+  const float t2 = gq_sat(d2 * f.r1.w);
+  const gq3 r2 = d - t2 * ac;
+  const float e2 = gq_dot(r2, r2);
+  const float t3 = gq_sat((d2 - d1 + f.r3.w) * f.r2.w);
+  const gq3 r3 = d - (1.0f - t3) * ab - t3 * ac;
+  const float e3 = gq_dot(r3, r3);
+  return inside ? dp : fminf(fminf(e1, e2), e3);
+}
+
+// closest point on the triangle (offset from a) + which feature won; used once per query for the best face
+__device__ __forceinline__ gq3 gq_tri_closest_off(const GqFace& f, gq3 d, float& dist2) {
+  const gq3 ab = gq_mk(f.r1.x, f.r1.y, f.r1.z), ac = gq_mk(f.r2.x, f.r2.y, f.r2.z);
+  const float d1 = gq_dot(ab, d), d2 = gq_dot(ac, d);
+  const float v = f.r3.x * d1 - f.r3.y * d2;
+  const float w = f.r3.z * d2 - f.r3.y * d1;
+  const float u = 1.0f - v - w;
+  const bool inside = fminf(fminf(v, w), u) >= 0.0f;
+  gq3 c = v * ab + w * ac;
+  gq3 r = d - c;
+  float best = gq_dot(r, r);
+  if (!inside) {
+    const float t1 = gq_sat(d1 * f.r0.w);
+    gq3 c1 = t1 * ab;
+    gq3 r1 = d - c1;
+    best = gq_dot(r1, r1);
+    c = c1;
+    const float t2 = gq_sat(d2 * f.r1.w);
+    gq3 c2 = t2 * ac;
+    gq3 r2 = d - c2;
+    const float e2 = gq_dot(r2, r2);
+    if (e2 < best) {
+      best = e2;
+      c = c2;
+    }
+    const float t3 = gq_sat((d2 - d1 + f.r3.w) * f.r2.w);
+    gq3 c3 = (1.0f - t3) * ab + t3 * ac;
+    gq3 r3 = d - c3;
+    const float e3 = gq_dot(r3, r3);
+    if (e3 < best) {
+      best = e3;
+      c = c3;
+    }
+  }
+  dist2 = best;
+  return c;
+}
+
+// full TorchSDF-contract result for the winning face
+struct GqSdfOut {
+  float dist2;
+  int sign;
+  gq3 normal, closest;
+};
+__device__ __forceinline__ GqSdfOut gq_tri_finish(const GqFace& f, gq3 p) {
+  const gq3 a = gq_mk(f.r0.x, f.r0.y, f.r0.z);
+  const gq3 ab = gq_mk(f.r1.x, f.r1.y, f.r1.z), ac = gq_mk(f.r2.x, f.r2.y, f.r2.z);
+  const gq3 d = p - a;
+  GqSdfOut o;
+  const gq3 off = gq_tri_closest_off(f, d, o.dist2);
+  o.closest = a + off;
+  const gq3 diff = d - off;
+  const gq3 fn = gq_cross(ab, ac);
+  o.sign = (gq_dot(diff, fn) >= 0.0f) ? 1 : -1;
+  if (o.dist2 > 0.0f) {
+    const float inv = 1.0f / sqrtf(o.dist2);
+    o.normal = inv * diff;
+  } else {
+    const float nn = gq_dot(fn, fn);
+    o.normal = (1.0f / sqrtf(fmaxf(nn, 1e-30f))) * fn;
+  }
+  return o;
+}
+
+// build one face record from three corners
+__device__ __forceinline__ GqFace gq_make_face(gq3 a, gq3 b, gq3 c) {
+  const gq3 ab = b - a, ac = c - a;
+  // setup-time only: the per-face constants are formed in double so that slivers do not lose nn to cancellation
+  const double abx = ab.x, aby = ab.y, abz = ab.z, acx = ac.x, acy = ac.y, acz = ac.z;
+  const double AA = abx * abx + aby * aby + abz * abz, CC = acx * acx + acy * acy + acz * acz;
+  const double AB = abx * acx + aby * acy + abz * acz;
+  const double BC = AA - 2.0 * AB + CC;
+  const double nn = AA * CC - AB * AB;
+  const float nanv = __builtin_nanf("");
+  GqFace f;
+  f.r0 = make_float4(a.x, a.y, a.z, AA > 0.0 ? (float)(1.0 / AA) : 0.0f);
+  f.r1 = make_float4(ab.x, ab.y, ab.z, CC > 0.0 ? (float)(1.0 / CC) : 0.0f);
+  f.r2 = make_float4(ac.x, ac.y, ac.z, BC > 0.0 ? (float)(1.0 / BC) : 0.0f);
+  const bool ok = nn > 1e-30 && nn > 1e-12 * AA * CC;
+  f.r3 = make_float4(ok ? (float)(CC / nn) : nanv, ok ? (float)(AB / nn) : nanv, ok ? (float)(AA / nn) : nanv,
+                     (float)(AA - AB));
+  return f;
+}

@@ -1,0 +1,72 @@
+"""``SpanMetricWrapper`` / ``GraspSpanMetricFactory`` with the reference's surface (metrics/ops/registry.py:18-140).
+
+``MetricType.GRASPQP`` (== ``--energy_type graspqp`` in scripts/fit.py:348-356) maps to the fused HIP op; the
+returned callable is used exactly like the reference's ``energy_fnc`` (core/energy.py:35-42):
+
+    E_fc, x = energy_fnc(contact_pts=, contact_normals=, sdf=, cog=, with_solution=True, svd_gain=)
+"""
+
+from enum import Enum
+
+import torch
+
+from ... import ops
+from ..solver.qp_solver import SQPLsqSolver
+from .span import OverallFrictionConeSpanMetric
+
+
+class SpanMetricWrapper(torch.nn.Module):
+    def __init__(self, metric=OverallFrictionConeSpanMetric, metric_kwargs: dict = {}):
+        super().__init__()
+        self.metric = metric
+        self._initialized = False
+        self.metric_kwargs = dict(metric_kwargs)
+        self.last_n_iter = None
+
+    def forward(self, contact_pts, contact_normals, cog=None, contact_threshold: float = 0.0, torque_weight: float = 5.0,
+                **kwargs):
+        svd_gain = kwargs.pop("svd_gain", 0.1)
+        values_gain = kwargs.pop("values_gain", 2.0)
+        with_solution = kwargs.pop("with_solution", False)
+        if not self._initialized:
+            self._max_limit = self.metric_kwargs.pop("max_limit", None)
+            self._friction = self.metric_kwargs.pop("friction", None)
+            self._n_cone = self.metric_kwargs.pop("n_cone_vecs", 4)
+            self.metric_kwargs.pop("solver_cls", None)
+            self._initialized = True
+        max_limit = 50.0 if self._max_limit is None else self._max_limit  # span.py:28 default
+        e, xs = ops.fc_energy(
+            contact_pts, contact_normals, cog, friction=0.2 if self._friction is None else self._friction,
+            n_cone_vecs=self._n_cone, torque_weight=torque_weight, max_limit=max_limit, svd_gain=svd_gain,
+            values_gain=values_gain,
+        )
+        if with_solution:
+            return e, xs
+        return e
+
+
+class GraspSpanMetricFactory:
+    class MetricType(Enum):
+        DEXGRASP = 1
+        TDG = 2
+        GRASPQP = 3
+        GRASPQP_SCIPY = 4
+        GRASPQP_EUCLIDIAN_SCIPY = 5
+
+    @staticmethod
+    def create(metric_type, solver_kwargs: dict = {}):
+        MT = GraspSpanMetricFactory.MetricType
+        if metric_type == MT.GRASPQP:
+            return SpanMetricWrapper(
+                OverallFrictionConeSpanMetric,
+                metric_kwargs={
+                    "solver_cls": SQPLsqSolver,
+                    "friction": solver_kwargs.pop("friction", None),
+                    "max_limit": solver_kwargs.pop("max_limit", None),
+                    **solver_kwargs,
+                },
+            )
+        raise NotImplementedError(
+            f"{metric_type}: only MetricType.GRASPQP is accelerated here; the other energy types of the reference "
+            "are plain torch modules and run unchanged on PyTorch-ROCm (out of scope, SURVEY 8f-3)"
+        )

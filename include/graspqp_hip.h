@@ -1,0 +1,167 @@
+/* graspqp_hip.h -- C ABI of libgraspqp_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the per-MALA*-iteration hot path of leggedrobotics/graspqp.  Every entry point
+ * replaces one interface of the (Python) reference; the reference file:line it stands in for is cited.
+ *
+ * Conventions
+ *   - all array arguments are DEVICE pointers unless the name ends in _host; tensors are dense, row-major,
+ *     float32 / int32 / int64 exactly as noted; the caller owns every buffer (no ownership transfer);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it and
+ *     graph-capturable (no allocation / synchronisation inside) except the *_create functions;
+ *   - return value 0 = ok, otherwise an error code; gq_last_error() returns a thread-local message;
+ *     nothing throws across the ABI;
+ *   - workspaces are caller-provided; their sizes come from the matching *_workspace_bytes function.
+ */
+#ifndef GRASPQP_HIP_H
+#define GRASPQP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int gq_version(void);
+const char* gq_last_error(void);
+int gq_device_check(int device, char* arch_out, int arch_len);
+
+/* ---- mesh signed distance: torchsdf.compute_sdf / index_vertices_by_faces ------------------------
+ * reference call sites: core/object_model.py:147,220  core/hand_model.py:352,953
+ * contract: dist_sq (N) squared distance; sign (N) int32 +1 outside / -1 inside; normal (N,3) unit
+ * (p - closest)/|p - closest| (may be NULL); closest (N,3).  Only dist_sq is differentiable, w.r.t. points. */
+typedef struct gqMeshSet gqMeshSet; /* n_mesh triangle soups resident on the device */
+int gq_meshset_create(const float* face_verts_host /* (sumF,3,3) */, const int32_t* face_offset_host /* (n_mesh+1) */,
+                      int n_mesh, gqMeshSet** out);
+int gq_meshset_destroy(gqMeshSet* ms);
+int gq_meshset_num_faces(const gqMeshSet* ms, int mesh /* -1 = all */, int64_t* n);
+int gq_sdf_workspace_bytes(int64_t n_faces, size_t* bytes);
+int gq_sdf_forward(const float* points /* (N,3) */, int64_t n_points, const float* face_verts /* (F,3,3) */,
+                   int64_t n_faces, float* dist_sq, int32_t* sign, float* normal, float* closest, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* object_model.py:217-220: query q uses mesh q / queries_per_mesh (one mesh per object) */
+int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_points, int64_t queries_per_mesh,
+                           float* dist_sq, int32_t* sign, float* normal, float* closest, void* stream);
+int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float* closest, int64_t n_points,
+                    float* grad_points, void* stream);
+
+/* ---- box-constrained QP: qpth.qp.QPFunction as used by SQPLsqSolver.solve --------------------------
+ * reference: metrics/solver/qp_solver.py:8,60-134 (QPFunction(maxIter=12, eps=5e-2), G = [I;-I], h = [u;-l]).
+ * lam / slack are (B, 2 nz): upper-bound block then lower-bound block.  lower/upper may be NULL (scalars used).
+ * gq_lsq_*: Q = A'A + ridge I, p = -A'b with A (B,m,nz), m <= 8, b (B,m) or NULL (= 0).  nz <= 64.          */
+int gq_boxqp_workspace_bytes(int64_t batch, int nz, int max_iter, size_t* bytes);
+int gq_boxqp_forward(const float* Q /* (B,nz,nz) */, const float* p /* (B,nz) or NULL */, const float* lower,
+                     const float* upper, float lower_s, float upper_s, int64_t batch, int nz, float eps, int max_iter,
+                     int not_improved_lim, float* x, float* lam, float* slack, int32_t* best_iter /* (B) or NULL */,
+                     int32_t* n_iter /* (1) or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+int gq_boxqp_backward(const float* Q, const float* lam, const float* slack, const float* grad_x, int64_t batch, int nz,
+                      float* dx /* (B,nz) = grad_p; grad_Q = (dx x' + x dx')/2 */,
+                      float* dlam /* (B,2nz); grad_h = -dlam */, void* stream);
+int gq_lsq_boxqp_forward(const float* A, const float* b, const float* lower, const float* upper, float lower_s,
+                         float upper_s, int64_t batch, int m, int nz, float ridge, float eps, int max_iter,
+                         int not_improved_lim, float* x, float* lam, float* slack, int32_t* best_iter, int32_t* n_iter,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, const float* grad_x, int64_t batch,
+                          int m, int nz, float ridge, float* dx, float* dlam, void* stream);
+
+/* ---- force-closure energy: energy_fnc for energy_type "graspqp" ------------------------------------
+ * reference: metrics/ops/span.py:263-295,313-415  metrics/ops/registry.py:31-89
+ * E_fc = values_gain (1/2 |F x|^2 + 0.01) exp(-svd_gain (prod sigma(F))^(1/6)), 1 <= x <= max_limit + 1.
+ * cog is (B,3).  gq_fc_backward must follow gq_fc_forward on the same workspace.                           */
+int gq_fc_workspace_bytes(int64_t batch, int n_contact, int n_cone, int max_iter, size_t* bytes);
+int gq_fc_forward(const float* contact_pts, const float* contact_normals, const float* cog, int64_t batch,
+                  int n_contact, int n_cone, float friction, float torque_weight, float max_limit, float svd_gain,
+                  float values_gain, float eps, int max_iter, float* e_fc /* (B) */,
+                  float* x_sum /* (B,n_contact) or NULL */, int32_t* n_iter, void* workspace, size_t workspace_bytes,
+                  void* stream);
+int gq_fc_backward(const float* contact_pts, const float* contact_normals, const float* cog, const float* grad_e,
+                   int64_t batch, int n_contact, int n_cone, float friction, float torque_weight, float svd_gain,
+                   float values_gain, float* grad_contact_pts, void* workspace, size_t workspace_bytes, void* stream);
+int gq_fc_peek(void* workspace, size_t workspace_bytes, int64_t batch, int n_contact, int n_cone, const float** F,
+               const float** x, const float** val, const float** svd);
+
+/* ---- hand kinematics: HandModel.set_parameters / fk / _set_contact_idxs -----------------------------
+ * reference: core/hand_model.py:762-766,787-873,1220-1267  utils/transforms.py:5-13
+ * The hand is described by a reduced kinematic tree (fixed joints folded, see graspqp_amd/hands/spec.py).
+ * hand_pose (B, 9 + n_dofs) = [t(3), rot6d(6), theta]; transforms are 3x4 row-major [R|t].                 */
+typedef struct gqHandDesc { /* all pointers HOST */
+  int32_t n_dofs, n_links, n_cand, n_spheres;
+  const int32_t* node_parent; /* (J) parent node, -1 = base; parents precede children */
+  const int32_t* node_type;   /* (J) 1 revolute, 2 prismatic */
+  const float* node_pre;      /* (J,12) fixed transform parent node frame -> joint frame */
+  const float* node_axis;     /* (J,3) unit axis in the joint frame */
+  const int32_t* link_node;   /* (L) node a mesh link rides on, -1 = base */
+  const float* link_offset;   /* (L,12) node frame -> link frame */
+  const float* cand_pos;      /* (C,3) contact candidates, link frame */
+  const float* cand_nrm;      /* (C,3) */
+  const int32_t* cand_link;   /* (C) */
+  const float* sphere;        /* (S,4) penetration spheres x y z r, link frame */
+  const int32_t* sphere_link; /* (S) non-decreasing */
+  const float* joints_lower;  /* (J) */
+  const float* joints_upper;  /* (J) */
+} gqHandDesc;
+typedef struct gqHand gqHand;
+int gq_hand_create(const gqHandDesc* desc, gqHand** out);
+int gq_hand_destroy(gqHand* h);
+int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes);
+int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx /* (B,n) */, int64_t batch,
+                  int n_contact, float* Rg /* (B,9) */, float* link_T /* (B,L,12) */, float* contact_points /* (B,n,3) */,
+                  float* contact_normals /* (B,n,3) */, float* sphere_centers /* (B,S,3) or NULL */, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* analytic backward (replaces autograd through pytorch_kinematics); the workspace must be the one written by
+ * gq_fk_forward for the same hand_pose.  Any gradient input may be NULL.  g_link_wrench (B,L,6) = (f, m about the
+ * hand origin) in the hand frame and g_Rt (B,12) come from gq_hand_pen_backward.                             */
+int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
+                   const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
+                   const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
+                   const float* g_R, float* grad_pose /* (B,9+J) */, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
+ * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.
+ * dis (B,P) = max over links of sqrt(d^2 + 1e-8) * (-sign); link (B,P) argmax; gvec (B,P,3) = d dis / d x_h. */
+int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
+                        int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
+                        const float* link_T, float* dis, int32_t* link, float* gvec, void* stream);
+int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
+                         int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
+                         const float* grad_dis /* (B,P) */, const int32_t* link, const float* gvec,
+                         float* link_wrench /* (B,L,6) */, float* gRt /* (B,12) */, void* stream);
+
+/* ---- self penetration: HandModel.self_penetration (E_spen), core/hand_model.py:989-1040 ------------------ */
+int gq_self_pen_forward(const gqHand* h, const float* sphere_centers /* (B,S,3) world */, int64_t batch,
+                        float* e_spen /* (B) */, float* g_centers /* (B,S,3) dE/dcentre */, void* stream);
+
+/* ---- energy composition: core/energy.py:25-28,47-62 and scripts/fit.py:434-438 ---------------------------- */
+int gq_contact_terms(const float* dist_sq, const int32_t* sign, const float* onrm, const float* closest,
+                     const float* contact_pts, const float* contact_normals, int64_t batch, int n_contact, float w_dis,
+                     float* obj_normal /* (B,n,3) = onrm*sign */, float* g_contact_pts, float* g_contact_normals,
+                     void* stream);
+int gq_row_energy(const float* dist_sq, const int32_t* sign, const float* onrm, const float* contact_normals,
+                  const float* hand_pose, const float* joints_lower, const float* joints_upper, const float* e_fc,
+                  const float* pen_dis, const float* e_spen, int64_t batch, int n_contact, int n_dofs,
+                  int64_t n_surface, float w_dis, float w_fc, float w_pen, float w_spen, float w_joints, float* e_dis,
+                  float* e_joints, float* e_pen, float* total, float* g_theta /* (B,J) */, float* g_pen /* (B,P) */,
+                  void* stream);
+int gq_axpy(float* y, const float* x, float a, int64_t n, void* stream);
+int gq_scale(float* y, const float* x, float a, int64_t n, void* stream);
+int gq_fill(float* y, float a, int64_t n, void* stream);
+
+/* ---- MALA* optimiser: MalaStar.try_step / accept_step, core/optimizer.py:199-273,289-340; fit.py:403-406,454-458
+ * random draws are inputs: u_switch (B,n) U[0,1), new_idx (B,n) in [0,C), u_accept (B) U[0,1).               */
+int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* contact_idx, const float* u_switch,
+                    const int64_t* new_idx, int64_t batch, int pose_dim, int n_contact, float step_size,
+                    int stepsize_period, float decay, float mu, float switch_possibility, int clip_grad,
+                    float* ema /* (B,D) in/out */, int64_t* step /* (B) in/out */, float* pose_out, int64_t* idx_out,
+                    float* step_size_out /* (B) or NULL */, float* g2_scratch /* (D) */, void* stream);
+int gq_zscore(const float* energy, int64_t n_obj, int64_t batch_each, float* z, void* stream);
+int gq_mala_accept(const float* new_energy, const float* u_accept, const float* z, const uint8_t* reset_mask,
+                   const int64_t* step, const float* pose_new, const int64_t* idx_new, const float* grad_new,
+                   int64_t batch, int pose_dim, int n_contact, float starting_temperature, float decay,
+                   int annealing_period, float* energy, float* pose, int64_t* idx, float* grad, uint8_t* accept,
+                   float* temperature, int n_terms, const float* terms_new, float* terms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRASPQP_HIP_H */

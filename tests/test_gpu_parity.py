@@ -1,0 +1,430 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the CPU oracle (oracle/ref_cpu, fp64) on the
+same seeded inputs and against the committed golden fixtures.  Floating-point tolerances follow the stated contract
+(SURVEY 8c / BASELINE.json north_star): total energy <= 1e-4 rel, E_fc <= 1e-4 rel at the median (the PDIPM iterate has
+an fp32 noise tail), gradients <= 1e-3 rel norm-wise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ref_cpu  # noqa: E402
+from ref_cpu import kin as okin  # noqa: E402
+from ref_cpu import mala as omala  # noqa: E402
+from ref_cpu import models as omodels  # noqa: E402
+from ref_cpu import qp as oqp  # noqa: E402
+from ref_cpu import sdf as osdf  # noqa: E402
+from ref_cpu import span as ospan  # noqa: E402
+
+from graspqp_amd.hands import get_hand_spec  # noqa: E402
+from graspqp_amd.utils import meshes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gq():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graspqp_amd import _C, ops, stepper
+
+    _C.lib()
+    return type("gq", (), {"ops": ops, "C": _C, "stepper": stepper})
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _rel(a, b, floor=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SDF
+# ---------------------------------------------------------------------------------------------------------------
+def _check_sdf(gq, fv, pts, tag):
+    d2, sg, nrm, cls = gq.ops.compute_sdf(torch.tensor(pts, device="cuda"), torch.tensor(fv, device="cuda"))
+    torch.cuda.synchronize()
+    od2, osg, onrm, ocls = osdf.compute_sdf(torch.tensor(pts, dtype=torch.float64), torch.tensor(fv, dtype=torch.float64))
+    d2, sg, nrm, cls = d2.cpu().numpy(), sg.cpu().numpy(), nrm.cpu().numpy(), cls.cpu().numpy()
+    od2, osg, onrm, ocls = od2.numpy(), osg.numpy(), onrm.numpy(), ocls.numpy()
+    # distances: fp32 round-off on coordinates of size ~0.1 -> absolute 1e-7 on the distance
+    np.testing.assert_allclose(np.sqrt(d2), np.sqrt(od2), rtol=1e-4, atol=2e-7, err_msg=tag)
+    far = np.sqrt(od2) > 1e-5
+    mism = (sg != osg) & far
+    assert mism.mean() <= 2e-3, f"{tag}: sign mismatch rate {mism.mean()}"
+    # closest points may legitimately differ when two features tie; the distance to the query must agree
+    dd = np.linalg.norm(pts - cls, axis=1)
+    np.testing.assert_allclose(dd, np.sqrt(od2), rtol=1e-4, atol=2e-7, err_msg=tag)
+    agree = np.linalg.norm(cls - ocls, axis=1) < 1e-5
+    assert agree.mean() > 0.99, f"{tag}: closest-point agreement {agree.mean()}"
+    ok = agree & far
+    np.testing.assert_allclose(nrm[ok], onrm[ok], atol=5e-3, err_msg=tag)
+
+
+@pytest.mark.parametrize("mesh", ["sphere", "box", "superquadric", "allegro_link"])
+def test_sdf_matches_oracle_wave_kernel(gq, mesh):
+    rng = np.random.default_rng(0)
+    if mesh == "sphere":
+        fv = meshes.icosphere(2, 0.05)
+    elif mesh == "box":
+        fv = meshes.box()
+    elif mesh == "superquadric":
+        fv = meshes.superquadric(3, 32, 16)
+    else:
+        fv = get_hand_spec("allegro").link_faces(3)
+    ext = np.abs(fv).max()
+    pts = (rng.normal(size=(3000, 3)) * ext * 0.8).astype(np.float32)
+    pts[:50] = fv.reshape(-1, 3)[rng.integers(0, fv.shape[0] * 3, 50)]  # queries exactly on vertices
+    _check_sdf(gq, fv, pts, mesh)
+
+
+def test_sdf_points_kernel_and_analytic_sphere(gq):
+    """>= 131072 queries take the point-per-lane kernel; also checked against the closed-form sphere distance."""
+    rng = np.random.default_rng(1)
+    fv = meshes.icosphere(3, 0.05)
+    pts = (rng.normal(size=(140000, 3)) * 0.05).astype(np.float32)
+    d2, sg, nrm, cls = gq.ops.compute_sdf(torch.tensor(pts, device="cuda"), torch.tensor(fv, device="cuda"))
+    r = np.linalg.norm(pts, axis=1)
+    sd = np.sqrt(d2.cpu().numpy()) * sg.cpu().numpy()
+    assert np.abs(sd - (r - 0.05)).max() < 3e-4  # faceting error of the 1280-face icosphere
+    sub = slice(0, 4000)
+    od2, osg, _, _ = osdf.compute_sdf(torch.tensor(pts[sub], dtype=torch.float64), torch.tensor(fv, dtype=torch.float64))
+    np.testing.assert_allclose(np.sqrt(d2.cpu().numpy()[sub]), np.sqrt(od2.numpy()), rtol=1e-4, atol=2e-7)
+    # wave kernel and point kernel agree bit-for-bit on the distance of the same queries
+    d2b, _, _, _ = gq.ops.compute_sdf(torch.tensor(pts[:5000], device="cuda"), torch.tensor(fv, device="cuda"))
+    assert torch.equal(d2b.cpu(), d2[:5000].cpu())
+
+
+def test_sdf_backward_and_edge_cases(gq):
+    fv = torch.tensor(meshes.box(), device="cuda")
+    p = torch.randn(257, 3, device="cuda").mul(0.06).requires_grad_()
+    d2, sg, nrm, cls = gq.ops.compute_sdf(p, fv)
+    w = torch.randn(257, device="cuda")
+    (d2 * w).sum().backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), (2 * (p.detach() - cls) * w[:, None]).cpu().numpy(), rtol=1e-6, atol=1e-9)
+    # empty query set and single query
+    e = gq.ops.compute_sdf(torch.zeros(0, 3, device="cuda"), fv)
+    assert e[0].shape == (0,) and e[3].shape == (0, 3)
+    one = gq.ops.compute_sdf(torch.tensor([[0.0, 0.0, 0.2]], device="cuda"), fv)
+    assert abs(float(one[0][0]) - 0.15**2) < 1e-6 and int(one[1][0]) == 1
+    with pytest.raises(ValueError):
+        gq.ops.compute_sdf(torch.zeros(4, 2, device="cuda"), fv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# QP
+# ---------------------------------------------------------------------------------------------------------------
+def test_qp_reference_known_answer(gq, golden_dir):
+    """reference tests/metrics/test_solver.py:5-27 through the SQPLsqSolver-compatible class."""
+    from graspqp_amd.metrics import SQPLsqSolver
+
+    g = _load(golden_dir, "kat_solver.npz")
+    A, b = torch.tensor(g["A"], device="cuda"), torch.tensor(g["b"], device="cuda")
+    solver = SQPLsqSolver.from_mat(A, b)
+    sol = solver(A, b, min_bound=-10.0, max_bound=1e3, init=0.1)
+    assert torch.allclose(sol, torch.zeros_like(sol), atol=1e-4)
+
+
+@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4)])
+def test_qp_iterate_matches_oracle(gq, golden_dir, n, k):
+    g = _load(golden_dir, f"span_n{n}_k{k}.npz")
+    F = torch.tensor(g["F"], dtype=torch.float64)
+    B, _, nz = F.shape
+    b0 = torch.zeros(B, 6, dtype=torch.float64)
+    val_o, x_o = oqp.lsq_box_qp(F, b0, 1.0, 21.0, box_form=True)
+    Fg = F.float().cuda().requires_grad_()
+    x = gq.ops.lsq_box_qp(Fg, None, 1.0, 21.0)
+    val = 0.5 * ((Fg @ x.unsqueeze(-1)).squeeze(-1) ** 2).sum(-1)
+    rel = _rel(2 * (val.detach().cpu().numpy() + 0.01), 2 * (val_o.numpy() + 0.01))
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert np.abs(x.detach().cpu().numpy() - x_o.numpy()).max() < 5e-2
+    assert (x.min() >= 1.0 - 1e-4) and (x.max() <= 21.0 + 1e-3)
+    # gradient of the value w.r.t. F (direct + implicit KKT part)
+    val.sum().backward()
+    Fo = F.clone().requires_grad_()
+    vo, _ = oqp.lsq_box_qp(Fo, b0, 1.0, 21.0, box_form=True)
+    vo.sum().backward()
+    ge = np.linalg.norm(Fg.grad.cpu().numpy() - Fo.grad.numpy()) / np.linalg.norm(Fo.grad.numpy())
+    assert ge < 2e-2, ge
+
+
+def test_qpfunction_level_boundary(gq):
+    """QPFunction(Q, p, G, h) with G = [I; -I]; wrong G is refused loudly."""
+    from graspqp_amd.metrics import QPFunction
+
+    torch.manual_seed(0)
+    B, nz = 8, 16
+    M = torch.randn(B, 6, nz, dtype=torch.float64)
+    Q = M.transpose(1, 2) @ M + 1e-2 * torch.eye(nz, dtype=torch.float64)
+    p = torch.randn(B, nz, dtype=torch.float64)
+    G = torch.cat([torch.eye(nz), -torch.eye(nz)]).double()
+    h = torch.cat([2 * torch.ones(B, nz), torch.ones(B, nz)], 1).double()
+    xo, _, _, nit = oqp.pdipm_forward(Q, p, G, h)
+    x = QPFunction(maxIter=12, eps=5e-2)(Q.float().cuda(), p.float().cuda(), G.float().cuda(), h.float().cuda())
+    assert np.abs(x.cpu().numpy() - xo.numpy()).max() < 2e-2
+    with pytest.raises(NotImplementedError):
+        QPFunction()(Q.float().cuda(), p.float().cuda(), (2 * G).float().cuda(), h.float().cuda())
+
+
+@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4)])
+def test_fc_energy_and_gradient(gq, golden_dir, n, k):
+    g = _load(golden_dir, f"span_n{n}_k{k}.npz")
+    pts = torch.tensor(g["contact_pts"], dtype=torch.float64)
+    nrm = torch.tensor(g["contact_normals"], dtype=torch.float64)
+    cog = torch.tensor(g["cog"], dtype=torch.float64)
+    po = pts.clone().requires_grad_()
+    eo, xso = ospan.e_fc(po, nrm, cog, k=k, box_form=True)
+    eo.sum().backward()
+    pg = pts.float().cuda().requires_grad_()
+    e, xs = gq.ops.fc_energy(pg, nrm.float().cuda(), cog.float().cuda(), n_cone_vecs=k)
+    e.sum().backward()
+    rel = _rel(e.detach().cpu().numpy(), eo.detach().numpy())
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    ge = np.linalg.norm(pg.grad.cpu().numpy() - po.grad.numpy()) / np.linalg.norm(po.grad.numpy())
+    assert ge < 2e-2, ge
+    # the grasp matrix itself is pinned by the reference's own span.py (fixture F)
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": k})
+    e2, _ = fn(contact_pts=pts.float().cuda(), contact_normals=nrm.float().cuda(), sdf=None, cog=cog.float().cuda(),
+               with_solution=True, svd_gain=0.1)
+    assert torch.allclose(e2, e.detach(), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kinematics, penetration
+# ---------------------------------------------------------------------------------------------------------------
+def _rand_pose(spec, B, seed, spread=0.12):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.nn.functional.normalize(torch.randn(B, 3, generator=g, dtype=torch.float64), dim=-1) * spread
+    six = torch.randn(B, 6, generator=g, dtype=torch.float64)
+    th = torch.tensor(spec.default_state, dtype=torch.float64)[None] + 0.3 * torch.randn(B, spec.n_dofs, generator=g, dtype=torch.float64)
+    return torch.cat([t, six, th], 1)
+
+
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3"])
+def test_fk_contacts_forward_backward(gq, hand_name):
+    spec = get_hand_spec(hand_name)
+    B, n = 6, 12
+    hp = _rand_pose(spec, B, 3)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(4))
+    oh = omodels.OracleHand(spec, torch.float64)
+    hpo = hp.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    sph = okin.sphere_centers_world(spec, oh.current_status, oh.global_rotation, oh.global_translation)
+    hand = gq.ops.HandHandle(spec)
+    hpg = hp.float().cuda().requires_grad_()
+    Rg, LT, cp, cn, sc, _ = gq.ops.fk_contacts(hpg, idx.cuda(), hand)
+    np.testing.assert_allclose(Rg.detach().cpu().numpy(), oh.global_rotation.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(LT.detach().cpu().numpy(), oh.current_status.detach().numpy()[:, :, :3, :], atol=3e-6)
+    np.testing.assert_allclose(cp.detach().cpu().numpy(), oh.contact_points.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(cn.detach().cpu().numpy(), oh.contact_normals.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(sc.detach().cpu().numpy(), sph.detach().numpy(), atol=3e-6)
+    g = torch.Generator().manual_seed(9)
+    w1, w2, w3 = (torch.randn(*s, generator=g, dtype=torch.float64) for s in ((B, n, 3), (B, n, 3), tuple(sph.shape)))
+    w4 = torch.randn(B, 3, 3, generator=g, dtype=torch.float64)
+    ((oh.contact_points * w1).sum() + (oh.contact_normals * w2).sum() + (sph * w3).sum() + (oh.global_rotation * w4).sum()).backward()
+    ((cp * w1.float().cuda()).sum() + (cn * w2.float().cuda()).sum() + (sc * w3.float().cuda()).sum() + (Rg * w4.float().cuda()).sum()).backward()
+    go, gg = oh.hand_pose.grad.numpy(), hpg.grad.cpu().numpy()
+    assert np.linalg.norm(gg - go) / np.linalg.norm(go) < 1e-4
+    np.testing.assert_allclose(gg, go, rtol=2e-3, atol=2e-4)
+
+
+def test_hand_penetration_and_self_penetration(gq):
+    spec = get_hand_spec("allegro")
+    n_obj, be, P = 2, 3, 300
+    B = n_obj * be
+    fvs = [meshes.icosphere(2, 0.05), meshes.superquadric(5, 24, 12)]
+    sps = [meshes.surface_points(f, P, oversample=4) for f in fvs]
+    hp = _rand_pose(spec, B, 11, spread=0.03)  # hand inside / around the object -> many penetrating points
+    hp[:, 9:] += 0.4  # curl the fingers -> self penetration
+    idx = torch.randint(spec.n_contact_candidates, (B, 4), generator=torch.Generator().manual_seed(2))
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject(fvs, sps, be, torch.float64)
+    hpo = hp.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    dis_o = oh.cal_distance(oo.surface_points_tensor)
+    spen_o = oh.self_penetration()
+    e_o = torch.where(dis_o <= 0, torch.zeros_like(dis_o), dis_o).sum(-1)
+    (e_o.sum() + spen_o.sum()).backward()
+
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=P)
+    om.initialize_from_meshes(fvs, surface_points_list=sps)
+    hpg = hp.float().cuda().requires_grad_()
+    hm.set_parameters(hpg, idx.cuda())
+    dis = hm.cal_distance(om.surface_points_each)
+    spen = hm.self_penetration()
+    e = torch.where(dis <= 0, torch.zeros_like(dis), dis).sum(-1)
+    (e.sum() + spen.sum()).backward()
+    d, do = dis.detach().cpu().numpy(), dis_o.detach().numpy()
+    assert (do > 1e-4).sum() > 20, "test scene must contain penetrating points"
+    big = np.abs(d - do) > 2e-6
+    assert big.mean() < 2e-3, f"distance disagreement rate {big.mean()}"
+    np.testing.assert_allclose(e.detach().cpu().numpy(), e_o.detach().numpy(), rtol=1e-4, atol=1e-6)
+    assert float(spen_o.sum()) > 0, "test scene must self-penetrate"
+    np.testing.assert_allclose(spen.detach().cpu().numpy(), spen_o.detach().numpy(), rtol=1e-4, atol=1e-7)
+    go, gg = oh.hand_pose.grad.numpy(), hm.hand_pose.grad.cpu().numpy()
+    assert np.linalg.norm(gg - go) / np.linalg.norm(go) < 2e-3
+    # the reference-style call with the row-expanded (B,P,3) tensor gives the same distances
+    dis2 = hm.cal_distance(om.surface_points_tensor)
+    assert torch.equal(dis2, dis)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole energy / whole iteration against the golden fixtures (reference energy.py / optimizer.py outputs)
+# ---------------------------------------------------------------------------------------------------------------
+def _stepper_from_fixture(gq, g, n_contact, **kw):
+    spec = get_hand_spec("allegro")
+    n_obj, be = int(g["n_obj"]), int(g["batch_size_each"])
+    fvs = [g[f"obj{i}_face_verts"] for i in range(n_obj)]
+    sps = np.stack([g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    hand = gq.ops.HandHandle(spec)
+    return gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(sps), be, n_contact, **kw)
+
+
+@pytest.mark.parametrize("tag,n", [("allegro_sphere_b4_n4", 4), ("allegro_sq_b6_n12", 12)])
+def test_energy_and_gradient_match_golden(gq, golden_dir, tag, n):
+    g = _load(golden_dir, f"energy_{tag}.npz")
+    st = _stepper_from_fixture(gq, g, n)
+    terms, total, grad = st.evaluate(torch.tensor(g["hand_pose"], dtype=torch.float32).cuda(), torch.tensor(g["contact_idx"]).cuda())
+    torch.cuda.synchronize()
+    for k in ("E_dis", "E_joints", "E_pen", "E_spen"):
+        np.testing.assert_allclose(terms[k].cpu().numpy(), g[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(terms["E_fc"].cpu().numpy(), g["E_fc"], rtol=5e-3, err_msg="E_fc")
+    rel = _rel(total.cpu().numpy(), g["total"])
+    assert np.median(rel) < 1e-4 and rel.max() < 2e-3, rel
+    gg, go = grad.cpu().numpy(), g["grad"]
+    assert np.linalg.norm(gg - go) / np.linalg.norm(go) < 5e-3
+    # autograd route == fused stepper (same kernels)
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    spec = get_hand_spec("allegro")
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=int(g["batch_size_each"]), num_samples=g["obj0_surface_points"].shape[0])
+    n_obj = int(g["n_obj"])
+    om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                              surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    hp = torch.tensor(g["hand_pose"], dtype=torch.float32).cuda().requires_grad_()
+    hm.set_parameters(hp, torch.tensor(g["contact_idx"]).cuda())
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"], svd_gain=0.1)
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    tot = sum(w[k] * v for k, v in losses.items())
+    tot.sum().backward()
+    np.testing.assert_allclose(tot.detach().cpu().numpy(), total.cpu().numpy(), rtol=2e-5)
+    ga = hm.hand_pose.grad.cpu().numpy()
+    assert np.linalg.norm(ga - gg) / np.linalg.norm(gg) < 1e-4
+
+
+def test_mala_iterations_match_reference_optimizer(gq, golden_dir):
+    """fit.py loop order + MalaStar semantics (fixture produced by the reference's own optimizer.py), replayed on the
+    GPU with the recorded random draws."""
+    g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
+    st = _stepper_from_fixture(gq, g, 4)
+    st.reset(torch.tensor(g["hand_pose0"]).cuda(), torch.tensor(g["contact_idx0"]).cuda())
+    np.testing.assert_allclose(st.energy.cpu().numpy(), g["energy0"], rtol=2e-3)
+    for s in range(1, int(g["n_steps"]) + 1):
+        st.step(draws=(torch.tensor(g[f"s{s}_u_switch"]).cuda(), torch.tensor(g[f"s{s}_new_idx"]).cuda(),
+                       torch.tensor(g[f"s{s}_u_accept"]).cuda()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(st.s_out.cpu().numpy(), g[f"s{s}_step_size"], rtol=1e-5)
+        np.testing.assert_allclose(st.pose_new.cpu().numpy(), g[f"s{s}_prop_pose"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(st.total_new.cpu().numpy(), g[f"s{s}_new_energy"], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(st.temperature.cpu().numpy(), g[f"s{s}_temperature"], rtol=1e-4)
+        assert st.accept.cpu().bool().tolist() == g[f"s{s}_accept"].tolist()
+        np.testing.assert_allclose(st.hand_pose.cpu().numpy(), g[f"s{s}_hand_pose"], rtol=1e-3, atol=1e-4)
+        assert st.contact_idx.cpu().tolist() == g[f"s{s}_contact_idx"].tolist()
+        np.testing.assert_allclose(st.energy.cpu().numpy(), g[f"s{s}_energy"], rtol=5e-3, atol=5e-3)
+        gref = g[f"s{s}_grad"]
+        assert np.linalg.norm(st.grad.cpu().numpy() - gref) <= 3e-2 * np.linalg.norm(gref) + 1e-2
+
+
+def test_mala_class_surface(gq, golden_dir):
+    """The MalaStar / HandModel / calculate_energy mirror runs a fit.py-style loop and matches the fused stepper."""
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.core.optimizer import MalaStar
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
+    be, n_obj = int(g["batch_size_each"]), int(g["n_obj"])
+    spec = get_hand_spec("allegro")
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=g["obj0_surface_points"].shape[0])
+    om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                              surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    hm.set_parameters(torch.tensor(g["hand_pose0"]).cuda().requires_grad_(), torch.tensor(g["contact_idx0"]).cuda())
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    names = list(w)
+
+    def total():
+        losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+        return sum(w[k] * v for k, v in losses.items())
+
+    opt = MalaStar(hm, switch_possibility=0.4, device="cuda", batch_size=be)
+    energy = total()
+    energy.sum().backward()
+    opt.zero_grad()
+    energy = energy.detach().clone()
+    for s in range(1, 4):
+        opt.try_step(draws=(torch.tensor(g[f"s{s}_u_switch"]).cuda(), torch.tensor(g[f"s{s}_new_idx"]).cuda()))
+        eb = energy.view(-1, be)
+        z = ((eb - eb.mean(-1, keepdim=True)) / eb.std(-1, keepdim=True)).view(-1)
+        opt.zero_grad()
+        new_energy = total()
+        new_energy.sum().backward()
+        with torch.no_grad():
+            accept, T = opt.accept_step(energy, new_energy, None, z, 1.0, u_accept=torch.tensor(g[f"s{s}_u_accept"]).cuda())
+        assert accept.cpu().tolist() == g[f"s{s}_accept"].tolist()
+        np.testing.assert_allclose(hm.hand_pose.detach().cpu().numpy(), g[f"s{s}_hand_pose"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(energy.cpu().numpy(), g[f"s{s}_energy"], rtol=5e-3, atol=5e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2: Allegro, 1 mesh, batch 256, 12 contacts)
+# ---------------------------------------------------------------------------------------------------------------
+def test_config2_properties_and_determinism(gq):
+    spec = get_hand_spec("allegro")
+    fv = meshes.superquadric(0)
+    sp = meshes.surface_points(fv, 2500, oversample=4)
+    hand = gq.ops.HandHandle(spec)
+    ms = gq.ops.MeshSet([fv])
+    B, n = 256, 12
+    hp = _rand_pose(spec, B, 21, spread=0.14).float().cuda()
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for rep in range(2):
+        st = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n, seed=7)
+        st.reset(hp, idx)
+        for _ in range(3):
+            st.step()
+        torch.cuda.synchronize()
+        outs.append((st.energy.clone(), st.hand_pose.clone(), st.grad.clone(), st.terms.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "iteration must be bitwise reproducible"
+    e, pose, grad, terms = outs[0]
+    assert torch.isfinite(e).all() and torch.isfinite(grad).all()
+    assert (terms[2] >= 0).all() and (terms[3] >= 0).all() and (terms[4] >= 0).all() and (terms[0] >= 0).all()
+    # a sample of rows against the oracle (fp64) on the accepted state
+    rows = [0, 17, 101, 255]
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject([fv], [sp], len(rows), torch.float64)
+    hpo = pose[rows].cpu().double().requires_grad_()
+    st2 = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n)
+    t2, tot2, g2 = st2.evaluate(pose, st.contact_idx)
+    oh.set_parameters(hpo, st.contact_idx[rows].cpu())
+    # batch-global QP stopping: the oracle sees 4 rows, the GPU 256 -> compare everything but E_fc tightly
+    lo = ref_cpu.calculate_energy(oh, oo, box_form=True)
+    for k, i in (("E_dis", 0), ("E_pen", 2), ("E_spen", 3), ("E_joints", 4)):
+        np.testing.assert_allclose(t2[k][rows].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    np.testing.assert_allclose(t2["E_fc"][rows].cpu().numpy(), lo["E_fc"].detach().numpy(), rtol=0.3)

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- grasp energy+grad evals/s of the MALA* hot path on MI355X (BASELINE.json metric).
+
+One "step" = one MALA* iteration (propose -> FK/contacts -> object SDF -> friction-cone QP -> E_dis/E_fc/E_joints/
+E_pen/E_spen -> backward to hand_pose -> accept) over the whole batch; one eval = one batch row through one step.
+Workload at N=1 = BASELINE configs[1]: Allegro, 1 YCB-style mesh, batch_size 256, n_contact 12 (synthetic mesh,
+2500 surface points).  N>1: every rank owns its own object(s) with the same per-rank batch (weak scaling, no
+collective in the loop; one optional all_gather of the final energies at the end).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def make_initial_state(spec, fv, B, n, seed):
+    """Hands on a shell of radius extent + U(0.05,0.1) around the object, palm roughly towards it, joints =
+    default + 0.1*range jitter, random contact indices (stands in for initialize_convex_hull)."""
+    g = torch.Generator().manual_seed(seed)
+    ext = float(np.abs(fv).max())
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    t = d * (ext + 0.05 + 0.05 * torch.rand(B, 1, generator=g))
+    z = -d  # hand forward axis (z for allegro) looks at the object
+    a = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)
+    x = torch.nn.functional.normalize(a - (a * z).sum(-1, keepdim=True) * z, dim=-1)
+    y = torch.linalg.cross(z, x)
+    six = torch.cat([x, y], dim=1)  # first two columns of R
+    lo, hi = torch.tensor(spec.joints_lower), torch.tensor(spec.joints_upper)
+    th = torch.tensor(spec.default_state)[None] + 0.1 * (hi - lo) * torch.randn(B, spec.n_dofs, generator=g).clamp(-2, 2)
+    th = torch.minimum(torch.maximum(th, lo), hi)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=g)
+    return torch.cat([t, six, th], 1).float(), idx
+
+
+def cpu_baseline(spec, fv, sp, n_contact, rows, reps):
+    """The oracle (CPU torch restatement of the reference algorithm, fp32) on a bounded sample of the same workload:
+    `rows` batch rows, full 2500 surface points, full meshes; energy + backward.  Baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu
+    from ref_cpu import models as omodels
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # a GPU box gives one GPU a 16-core share; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    hp, idx = make_initial_state(spec, fv, rows, n_contact, 123)
+    oh = omodels.OracleHand(spec, torch.float32)
+    oo = omodels.OracleObject([fv], [sp], rows, torch.float32)
+
+    def one():
+        h = hp.clone().requires_grad_()
+        oh.set_parameters(h, idx)
+        losses = ref_cpu.calculate_energy(oh, oo)  # qpth-form PDIPM (2nz x 2nz Schur system), brute-force SDF
+        ref_cpu.total_energy(losses).sum().backward()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": rows / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows x {reps} energy+grad evaluations of the same workload (Allegro, n_contact={n_contact}, "
+                      f"{fv.shape[0]}-face mesh, 2500 surface points), oracle/ref_cpu fp32, {dt:.2f} s each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--n_contact", type=int, default=12)
+    ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
+    ap.add_argument("--hand", default="allegro")
+    ap.add_argument("--graph", type=int, default=0, help="replay the iteration from a hipGraph (no per-kernel events)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_rows", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+
+    from graspqp_amd import ops
+    from graspqp_amd.hands import get_hand_spec
+    from graspqp_amd.parallel import shard_objects
+    from graspqp_amd.stepper import GraspStepper
+    from graspqp_amd.utils import meshes
+
+    spec = get_hand_spec(args.hand)
+    # object ids are global; rank r owns the contiguous block shard_objects gives it (whole objects per rank)
+    my_objs = shard_objects(args.n_objects * world, world, rank)
+    fvs = [meshes.superquadric(o) for o in my_objs]
+    sps = [meshes.surface_points(f, 2500, oversample=4, seed=42) for f in fvs]
+    B = len(my_objs) * args.batch_size
+    hand = ops.HandHandle(spec)
+    st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact, seed=1 + rank)
+    hps, idxs = zip(*[make_initial_state(spec, f, args.batch_size, args.n_contact, 1000 + o) for f, o in zip(fvs, my_objs)])
+    st.reset(torch.cat(hps).cuda(), torch.cat(idxs).cuda())
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.graph:
+        st.capture()
+    for _ in range(args.warmup):
+        st.step()
+    sync()
+    if not args.graph:
+        st.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step()
+    sync()
+    dt = time.perf_counter() - t0
+    evs = st.kernel_events
+    st.kernel_events = None
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # optional gather of the final energies (the only collective of a run; 1 KB per rank)
+        out = [torch.empty_like(st.energy) for _ in range(world)]
+        dist.all_gather(out, st.energy)
+    assert torch.isfinite(st.energy).all(), "non-finite energies"
+
+    if rank == 0:
+        total_evals = B * world * args.steps
+        nf = hand.links.n_faces
+        roof = None
+        if evs:
+            k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            # algorithmic bytes of the hand-penetration query (dist-only variant): 16 B per (point, link)
+            # query + 36 B per link-mesh face once per launch
+            alg = B * st.P * hand.L * 16 + nf * 36
+            ach = alg / (k_ms * 1e-3) / 1e9
+            pair_tests = B * st.P * nf
+            roof = {"bound": "hbm", "kernel": "gq_hand_pen_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                    "frac": ach / 8000.0, "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": alg,
+                    "point_triangle_tests_per_s": pair_tests / (k_ms * 1e-3),
+                    "fp32_valu_frac_at_58_flop_per_test": pair_tests * 58 / (k_ms * 1e-3) / 157.3e12}
+        res = {
+            "metric": "grasp energy+grad evals/sec (Allegro, n_contact=12)", "value": total_evals / dt, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.hand}, {args.n_objects} YCB-style superquadric mesh(es) per GPU "
+                                   f"({fvs[0].shape[0]} faces), batch_size={args.batch_size} each, n_contact={args.n_contact}, "
+                                   f"2500 surface points, 4-edge friction cones (BASELINE configs[1])",
+                       "rows_per_gpu": B, "hip_graph": bool(args.graph)},
+            "mean_energy": float(st.energy.mean()), "accept_rate_last": float(st.accept.float().mean()),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(spec, fvs[0], sps[0], args.n_contact, args.cpu_rows, 2)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,7 @@ class GraspStepper:
                                     int(self.fc["max_iter"]))
         self.fc_ws = ops._ws(self.fc_nb, self.dev)
         self._graph = None
+        self.kernel_events = None
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
     def _evaluate(self, pose, idx, st):
@@ -99,8 +100,15 @@ class GraspStepper:
           float(fc["friction"]), float(fc["torque_weight"]), float(fc["max_limit"]), float(fc["svd_gain"]),
           float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
           _C.ptr(self.fc_ws), self.fc_nb, st)
+        ev = self.kernel_events
+        if ev is not None:  # bench.py: HIP events around the dominant kernel, on the stream it is launched on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         C("gq_hand_pen_forward", self.hand.links.handle, f32(self.surf), self.n_obj, P, self.be, f32(pose), self.D,
           f32(self.Rg), f32(self.link_T), f32(self.pen_dis), i32(self.pen_link), f32(self.pen_gvec), st)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         if self.S > 0:
             C("gq_self_pen_forward", self.hand.handle, f32(self.spheres), B, f32(e_spen), f32(self.g_sph), st)
             C("gq_scale", f32(self.g_sph_w), f32(self.g_sph), float(w["E_spen"]), B * self.S * 3, st)

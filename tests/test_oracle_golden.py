@@ -86,7 +86,7 @@ def test_energy_matches_reference_composition(golden_dir, tag):
 def test_mala_loop_matches_reference_optimizer(golden_dir):
     """reference core/optimizer.py::MalaStar + fit.py loop order, replayed with the recorded draws."""
     g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
-    dt = torch.float32
+    dt = torch.float64
     spec, hand, obj = _scene(g, "allegro", dt)
     be = int(g["batch_size_each"])
     hp = torch.tensor(g["hand_pose0"], dtype=dt)
@@ -100,7 +100,7 @@ def test_mala_loop_matches_reference_optimizer(golden_dir):
         hp2, idx2, ema, step, ss = mala.propose(
             hp, grad, ema, step, idx, torch.tensor(g[f"s{s}_u_switch"]), torch.tensor(g[f"s{s}_new_idx"]))
         np.testing.assert_allclose(ss.numpy(), g[f"s{s}_step_size"], rtol=1e-6)
-        np.testing.assert_allclose(hp2.numpy(), g[f"s{s}_prop_pose"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(hp2.numpy(), g[f"s{s}_prop_pose"], rtol=1e-6, atol=1e-7)
         z = mala.z_score(energy, be)
         hpr = hp2.clone().requires_grad_()
         hand.set_parameters(hpr, idx2)
@@ -108,7 +108,7 @@ def test_mala_loop_matches_reference_optimizer(golden_dir):
         new_e = ref_cpu.total_energy(losses)
         new_e.sum().backward()
         g2 = hand.hand_pose.grad.detach()
-        np.testing.assert_allclose(new_e.detach().numpy(), g[f"s{s}_new_energy"], rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(new_e.detach().numpy(), g[f"s{s}_new_energy"], rtol=1e-6)
         acc, T = mala.accept(energy, new_e.detach(), step, torch.tensor(g[f"s{s}_u_accept"]), z=z)
         np.testing.assert_allclose(T.numpy(), g[f"s{s}_temperature"], rtol=1e-5)
         assert acc.tolist() == g[f"s{s}_accept"].tolist()
@@ -116,9 +116,9 @@ def test_mala_loop_matches_reference_optimizer(golden_dir):
         idx = mala.merge(acc, idx2, idx)
         grad = mala.merge(acc, g2, grad)
         energy = mala.merge(acc, new_e.detach(), energy)
-        np.testing.assert_allclose(hp.numpy(), g[f"s{s}_hand_pose"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(hp.numpy(), g[f"s{s}_hand_pose"], rtol=1e-6, atol=1e-7)
         assert idx.tolist() == g[f"s{s}_contact_idx"].tolist()
-        np.testing.assert_allclose(energy.numpy(), g[f"s{s}_energy"], rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(energy.numpy(), g[f"s{s}_energy"], rtol=1e-6)
         gref = g[f"s{s}_grad"]
-        assert np.linalg.norm(grad.numpy() - gref) <= 2e-2 * np.linalg.norm(gref) + 1e-3
-        np.testing.assert_allclose(ema.numpy(), g[f"s{s}_ema"], rtol=5e-2, atol=1e-4)
+        assert np.linalg.norm(grad.numpy() - gref) <= 1e-5 * np.linalg.norm(gref)
+        np.testing.assert_allclose(ema.numpy(), g[f"s{s}_ema"], rtol=1e-5, atol=1e-9)

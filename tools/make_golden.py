@@ -207,7 +207,9 @@ class _Recorder:
 
 def gen_mala(ref_energy, ref_opt):
     tag, hand_name, n_obj, be, n, seed, n_steps = "allegro_sphere_b8_n4", "allegro", 2, 4, 4, 21, 5
-    dtype = torch.float32
+    # fp64 models under the reference's (fp32-typed) optimizer: the trajectory is then free of the fp32 noise of a
+    # CPU PDIPM and serves as the high-accuracy reference for both the fp64 oracle replay and the fp32 GPU path
+    dtype = torch.float64
     spec, hand, obj, hp, idx, fvs, sps = make_scene(hand_name, n_obj, be, n, dtype, seed, "sphere", n_surface=400)
     B = n_obj * be
     hp0 = hp.clone().requires_grad_()

@@ -327,29 +327,56 @@ def test_energy_and_gradient_match_golden(gq, golden_dir, tag, n):
 
 
 def test_mala_iterations_match_reference_optimizer(gq, golden_dir):
-    """fit.py loop order + MalaStar semantics (fixture produced by the reference's own optimizer.py), replayed on the
-    GPU with the recorded random draws."""
+    """fit.py loop order + MalaStar semantics against the fixture produced by the reference's own optimizer.py.
+
+    Teacher-forced: before every iteration the stepper state is set to the fixture's accepted state, then ONE
+    iteration runs on the GPU with the recorded random draws.  (A free-running comparison is dominated by the
+    chaotic sensitivity of the trajectory: d E / d pose ~ 3e3, so fp32 round-off in one proposal moves later
+    energies by O(1); that is covered, with matching tolerances, by test_mala_free_running.)"""
     g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
     st = _stepper_from_fixture(gq, g, 4)
-    st.reset(torch.tensor(g["hand_pose0"]).cuda(), torch.tensor(g["contact_idx0"]).cuda())
-    np.testing.assert_allclose(st.energy.cpu().numpy(), g["energy0"], rtol=2e-3)
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    st.reset(f32("hand_pose0"), torch.tensor(g["contact_idx0"]).cuda())
+    np.testing.assert_allclose(st.energy.cpu().numpy(), g["energy0"], rtol=2e-4)
     for s in range(1, int(g["n_steps"]) + 1):
-        st.step(draws=(torch.tensor(g[f"s{s}_u_switch"]).cuda(), torch.tensor(g[f"s{s}_new_idx"]).cuda(),
-                       torch.tensor(g[f"s{s}_u_accept"]).cuda()))
+        if s > 1:
+            st.hand_pose.copy_(f32(f"s{s-1}_hand_pose"))
+            st.contact_idx.copy_(torch.tensor(g[f"s{s-1}_contact_idx"]).cuda())
+            st.grad.copy_(f32(f"s{s-1}_grad"))
+            st.energy.copy_(f32(f"s{s-1}_energy"))
+            st.ema.copy_(f32(f"s{s-1}_ema"))
+            st.step_count.fill_(s - 1)
+        st.step(draws=(f32(f"s{s}_u_switch"), torch.tensor(g[f"s{s}_new_idx"]).cuda(), f32(f"s{s}_u_accept")))
         torch.cuda.synchronize()
         np.testing.assert_allclose(st.s_out.cpu().numpy(), g[f"s{s}_step_size"], rtol=1e-5)
-        # the proposal moves by step_size * g / rms(g); a surface point that lies within fp32 noise of a link face
-        # flips its TorchSDF sign (dis = -sign*sqrt(d^2+1e-8) jumps by 2e-4) and kicks single gradient components,
-        # in the reference as much as here -> tolerance = 0.3 * step_size
-        np.testing.assert_allclose(st.pose_new.cpu().numpy(), g[f"s{s}_prop_pose"], rtol=1e-3, atol=1.5e-3)
-        np.testing.assert_allclose(st.total_new.cpu().numpy(), g[f"s{s}_new_energy"], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(st.z.cpu().numpy(), g[f"s{s}_z"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(st.pose_new.cpu().numpy(), g[f"s{s}_prop_pose"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(st.ema.cpu().numpy(), g[f"s{s}_ema"], rtol=1e-4, atol=1e-7)
+        rel = _rel(st.total_new.cpu().numpy(), g[f"s{s}_new_energy"])
+        assert rel.max() < 3e-4, rel  # pose carries fp32 round-off (1e-7 * dE/dpose 3e3) on top of the 1e-4 contract
         np.testing.assert_allclose(st.temperature.cpu().numpy(), g[f"s{s}_temperature"], rtol=1e-4)
+        assert st.accept.cpu().bool().tolist() == g[f"s{s}_accept"].tolist()
+        np.testing.assert_allclose(st.hand_pose.cpu().numpy(), g[f"s{s}_hand_pose"], rtol=1e-5, atol=2e-6)
+        assert st.contact_idx.cpu().tolist() == g[f"s{s}_contact_idx"].tolist()
+        assert _rel(st.energy.cpu().numpy(), g[f"s{s}_energy"]).max() < 3e-4
+        gref = g[f"s{s}_grad"]
+        assert np.linalg.norm(st.grad.cpu().numpy() - gref) <= 2e-2 * np.linalg.norm(gref)
+
+
+def test_mala_free_running(gq, golden_dir):
+    """Free-running 5 iterations from the fixture's initial state: accept decisions identical, poses within
+    0.3 * step_size, energies within |dE/dpose| * that."""
+    g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
+    st = _stepper_from_fixture(gq, g, 4)
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    st.reset(f32("hand_pose0"), torch.tensor(g["contact_idx0"]).cuda())
+    for s in range(1, int(g["n_steps"]) + 1):
+        st.step(draws=(f32(f"s{s}_u_switch"), torch.tensor(g[f"s{s}_new_idx"]).cuda(), f32(f"s{s}_u_accept")))
+        torch.cuda.synchronize()
         assert st.accept.cpu().bool().tolist() == g[f"s{s}_accept"].tolist()
         np.testing.assert_allclose(st.hand_pose.cpu().numpy(), g[f"s{s}_hand_pose"], rtol=1e-3, atol=1.5e-3)
         assert st.contact_idx.cpu().tolist() == g[f"s{s}_contact_idx"].tolist()
-        np.testing.assert_allclose(st.energy.cpu().numpy(), g[f"s{s}_energy"], rtol=5e-3, atol=5e-3)
-        gref = g[f"s{s}_grad"]
-        assert np.linalg.norm(st.grad.cpu().numpy() - gref) <= 6e-2 * np.linalg.norm(gref) + 1e-2
+        np.testing.assert_allclose(st.energy.cpu().numpy(), g[f"s{s}_energy"], rtol=6e-2)
 
 
 def test_mala_class_surface(gq, golden_dir):
@@ -367,7 +394,8 @@ def test_mala_class_surface(gq, golden_dir):
     om = ObjectModel(batch_size_each=be, num_samples=g["obj0_surface_points"].shape[0])
     om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
                               surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
-    hm.set_parameters(torch.tensor(g["hand_pose0"]).cuda().requires_grad_(), torch.tensor(g["contact_idx0"]).cuda())
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    hm.set_parameters(f32("hand_pose0").requires_grad_(), torch.tensor(g["contact_idx0"]).cuda())
     fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
     w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
     names = list(w)
@@ -382,17 +410,17 @@ def test_mala_class_surface(gq, golden_dir):
     opt.zero_grad()
     energy = energy.detach().clone()
     for s in range(1, 4):
-        opt.try_step(draws=(torch.tensor(g[f"s{s}_u_switch"]).cuda(), torch.tensor(g[f"s{s}_new_idx"]).cuda()))
+        opt.try_step(draws=(f32(f"s{s}_u_switch"), torch.tensor(g[f"s{s}_new_idx"]).cuda()))
         eb = energy.view(-1, be)
         z = ((eb - eb.mean(-1, keepdim=True)) / eb.std(-1, keepdim=True)).view(-1)
         opt.zero_grad()
         new_energy = total()
         new_energy.sum().backward()
         with torch.no_grad():
-            accept, T = opt.accept_step(energy, new_energy, None, z, 1.0, u_accept=torch.tensor(g[f"s{s}_u_accept"]).cuda())
+            accept, T = opt.accept_step(energy, new_energy, None, z, 1.0, u_accept=f32(f"s{s}_u_accept"))
         assert accept.cpu().tolist() == g[f"s{s}_accept"].tolist()
         np.testing.assert_allclose(hm.hand_pose.detach().cpu().numpy(), g[f"s{s}_hand_pose"], rtol=1e-3, atol=1.5e-3)
-        np.testing.assert_allclose(energy.cpu().numpy(), g[f"s{s}_energy"], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(energy.cpu().numpy(), g[f"s{s}_energy"], rtol=2e-2)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[],
     )
 
     object_model.attach(hand_model)
-    distances = hand_model.cal_distance(object_model.surface_points_each)
+    distances = hand_model.cal_distance(object_model.surface_points_each, penetration_only=True)  # only dis > 0 is used
     distances = torch.where(distances <= 0, torch.zeros_like(distances), distances)
     losses["E_pen"] = distances.sum(-1)
     losses["E_spen"] = hand_model.self_penetration()

@@ -100,7 +100,7 @@ class HandModel:
         self._sphere_centers = sc
 
     # reference hand_model.py:875-987
-    def cal_distance(self, x):
+    def cal_distance(self, x, penetration_only=False):
         """x: (B,N,3) object surface points, identical for the rows of one object (object_model.py:182-184), or the
         un-expanded (n_obj,N,3).  Returns (B,N) max-over-links signed distance, inside positive."""
         B = self.hand_pose.shape[0]
@@ -116,7 +116,7 @@ class HandModel:
         # the kinematic state (Rg, link transforms, FK workspace) is the one written by the last set_parameters
         return ops.hand_pen(self.hand_pose, surf, be, self._hand, self.contact_point_indices,
                             self.global_rotation.detach(), self.current_status.detach(), self._fk_ws,
-                            self._fk_ws.numel())
+                            self._fk_ws.numel(), penetration_only)
 
     # reference hand_model.py:989-1040
     def self_penetration(self):

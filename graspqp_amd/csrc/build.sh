@@ -7,8 +7,18 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
 OBJS=()
+deps() {  # headers each translation unit includes
+  case "$1" in
+    qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
+    sdf) echo "common.h tri.h" ;;
+    *) echo "common.h" ;;
+  esac
+}
 for f in api qp qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc loop; do
-  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ -n "$(find "$HERE" -name '*.h' -newer "$OUT/$f.o" 2>/dev/null)" ]; then
+  stale=0
+  [ -f "$OUT/$f.o" ] || stale=1
+  for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done
+  if [ $stale = 1 ]; then
     echo "[build] hipcc $f.hip"
     "$HIPCC" $FLAGS ${GQ_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o" &
   fi

@@ -408,7 +408,7 @@ int gq_hand_destroy(gqHand* h) {
   void* p[] = {h->node_parent, h->node_type, h->node_pre, h->node_axis, h->link_node, h->link_offset, h->cand_pos,
                h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off};
   for (void* q : p)
-    if (q) hipFree(q);
+    if (q) (void)hipFree(q);
   delete h;
   return GQ_OK;
 }

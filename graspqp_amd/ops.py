@@ -399,7 +399,7 @@ class _HandPen(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb):
+    def forward(ctx, hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only=False):
         hp = _c(hand_pose.detach())
         sp = _c(surface_points)
         n_obj, P, _ = sp.shape
@@ -409,7 +409,8 @@ class _HandPen(torch.autograd.Function):
         link = torch.empty(B, P, dtype=torch.int32, device=dev)
         gvec = torch.empty(B, P, 3, device=dev)
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
-                _C.f32(Rg), _C.f32(LT), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.stream_ptr())
+                _C.f32(Rg), _C.f32(LT), int(bool(penetration_only)), _C.f32(dis), _C.i32(link), _C.f32(gvec),
+                _C.stream_ptr())
         ctx.save_for_backward(hp, sp, idx, Rg, LT, ws, link, gvec)
         ctx.hand, ctx.batch_each, ctx.nb = hand, int(batch_each), nb
         return dis
@@ -426,11 +427,11 @@ class _HandPen(torch.autograd.Function):
         _C.call("gq_hand_pen_backward", hand.L, _C.f32(sp), n_obj, P, ctx.batch_each, _C.f32(hp), hp.shape[1], _C.f32(Rg),
                 _C.f32(_c(g)), _C.i32(link), _C.f32(gvec), _C.f32(wrench), _C.f32(gRt), _C.stream_ptr())
         gp = _fk_backward(hand, hp, idx, Rg, LT, ws, ctx.nb, None, None, None, wrench, gRt, None, None)
-        return gp, None, None, None, None, None, None, None, None
+        return gp, None, None, None, None, None, None, None, None, None
 
 
-def hand_pen(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb):
-    return _HandPen.apply(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb)
+def hand_pen(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only=False):
+    return _HandPen.apply(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only)
 
 
 class _SelfPen(torch.autograd.Function):

@@ -25,7 +25,8 @@ DEFAULT_WEIGHTS = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, 
 
 class GraspStepper:
     def __init__(self, hand: ops.HandHandle, object_meshes: ops.MeshSet, surface_points: torch.Tensor, batch_each: int,
-                 n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1):
+                 n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
+                 penetration_only: bool = True):
         self.hand, self.objs = hand, object_meshes
         self.dev = torch.device(device)
         self.surf = surface_points.to(self.dev, torch.float32).contiguous()  # (n_obj,P,3)
@@ -84,12 +85,13 @@ class GraspStepper:
         self.fc_ws = ops._ws(self.fc_nb, self.dev)
         self._graph = None
         self.kernel_events = None
+        self.penetration_only = bool(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
-    def _evaluate(self, pose, idx, st):
+    def _eval_pre(self, pose, idx, st):
         B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
         C, f32, i32, i64 = _C.call, _C.f32, _C.i32, _C.i64
-        e_dis, e_fc, e_pen, e_spen, e_joints = (self.terms_new[i] for i in range(5))
+        e_fc = self.terms_new[1]
         C("gq_fk_forward", self.hand.handle, f32(pose), i64(idx), B, n, f32(self.Rg), f32(self.link_T), f32(self.cpts),
           f32(self.cnrm), f32(self.spheres) if self.S > 0 else None, _C.ptr(self.fk_ws), self.fk_nb, st)
         C("gq_sdf_forward_meshset", self.objs.handle, f32(self.cpts), B * n, self.be * n, f32(self.d2), i32(self.sgn),
@@ -100,15 +102,17 @@ class GraspStepper:
           float(fc["friction"]), float(fc["torque_weight"]), float(fc["max_limit"]), float(fc["svd_gain"]),
           float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
           _C.ptr(self.fc_ws), self.fc_nb, st)
-        ev = self.kernel_events
-        if ev is not None:  # bench.py: HIP events around the dominant kernel, on the stream it is launched on
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        C("gq_hand_pen_forward", self.hand.links.handle, f32(self.surf), self.n_obj, P, self.be, f32(pose), self.D,
-          f32(self.Rg), f32(self.link_T), f32(self.pen_dis), i32(self.pen_link), f32(self.pen_gvec), st)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
+
+    def _eval_pen(self, pose, st):
+        """The dominant kernel, kept as a launch of its own so bench.py can bracket it with HIP events."""
+        _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
+                _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
+                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec), st)
+
+    def _eval_post(self, pose, idx, st):
+        B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
+        C, f32, i32, i64 = _C.call, _C.f32, _C.i32, _C.i64
+        e_dis, e_fc, e_pen, e_spen, e_joints = (self.terms_new[i] for i in range(5))
         if self.S > 0:
             C("gq_self_pen_forward", self.hand.handle, f32(self.spheres), B, f32(e_spen), f32(self.g_sph), st)
             C("gq_scale", f32(self.g_sph_w), f32(self.g_sph), float(w["E_spen"]), B * self.S * 3, st)
@@ -128,6 +132,18 @@ class GraspStepper:
         C("gq_fk_backward", self.hand.handle, f32(pose), i64(idx), B, n, f32(self.Rg), f32(self.link_T), f32(self.g_cpts),
           f32(self.g_cnrm), f32(self.g_sph_w) if self.S > 0 else None, f32(self.wrench), f32(self.gRt), f32(self.g_theta),
           None, f32(self.grad_new), _C.ptr(self.fk_ws), self.fk_nb, st)
+
+    def _evaluate(self, pose, idx, st):
+        self._eval_pre(pose, idx, st)
+        ev = self.kernel_events
+        if ev is not None:  # bench.py: HIP events around the dominant kernel, on the stream it is launched on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._eval_pen(pose, st)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
+        self._eval_post(pose, idx, st)
 
     def evaluate(self, pose, idx):
         """Energy terms, total and d total / d pose at an arbitrary (pose, idx); returns clones."""
@@ -154,7 +170,7 @@ class GraspStepper:
         self.new_idx.random_(0, self.hand.spec.n_contact_candidates, generator=self.gen)
         self.u_accept.uniform_(generator=self.gen)
 
-    def _step_kernels(self, st):
+    def _step_head(self, st):
         B, D, n, m = self.B, self.D, self.n, self.mala
         C, f32, i64 = _C.call, _C.f32, _C.i64
         C("gq_mala_propose", f32(self.hand_pose), f32(self.grad), i64(self.contact_idx), f32(self.u_switch),
@@ -162,12 +178,27 @@ class GraspStepper:
           float(m["mu"]), float(m["switch_possibility"]), int(bool(m["clip_grad"])), f32(self.ema), i64(self.step_count),
           f32(self.pose_new), i64(self.idx_new), f32(self.s_out), f32(self.g2), st)
         C("gq_zscore", f32(self.energy), self.n_obj, self.be, f32(self.z), st)  # z-score of the OLD energies
-        self._evaluate(self.pose_new, self.idx_new, st)
+        self._eval_pre(self.pose_new, self.idx_new, st)
+
+    def _step_tail(self, st):
+        B, D, n, m = self.B, self.D, self.n, self.mala
+        C, f32, i64 = _C.call, _C.f32, _C.i64
+        self._eval_post(self.pose_new, self.idx_new, st)
         C("gq_mala_accept", f32(self.total_new), f32(self.u_accept), f32(self.z), None,
           i64(self.step_count), f32(self.pose_new), i64(self.idx_new), f32(self.grad_new), B, D, n,
           float(m["starting_temperature"]), float(m["temperature_decay"]), int(m["annealing_period"]), f32(self.energy),
           f32(self.hand_pose), i64(self.contact_idx), f32(self.grad), _C.u8(self.accept), f32(self.temperature), 5,
           f32(self.terms_new), f32(self.terms), st)
+
+    def _pen_timed(self, st):
+        ev = self.kernel_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._eval_pen(self.pose_new, st)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
 
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""
@@ -177,21 +208,40 @@ class GraspStepper:
             self.u_switch.copy_(draws[0])
             self.new_idx.copy_(draws[1])
             self.u_accept.copy_(draws[2])
+        st = _C.stream_ptr()
         if self._graph is not None:
-            self._graph.replay()
+            self._graph[0].replay()
+            self._pen_timed(st)
+            self._graph[1].replay()
         else:
-            self._step_kernels(_C.stream_ptr())
+            self._step_head(st)
+            self._pen_timed(st)
+            self._step_tail(st)
 
     def capture(self):
-        """Capture the kernel sequence of one iteration into a hipGraph (draws stay outside the graph)."""
+        """Capture one iteration into two hipGraphs (everything before / after the hand-penetration kernel, which
+        stays an ordinary launch so it can be bracketed by events).  The state is saved and restored around the
+        warm-up + capture passes, so capturing does not advance the chain."""
+        saved = [t.clone() for t in (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema,
+                                     self.step_count, self.terms)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._step_kernels(_C.stream_ptr())  # warm-up on the side stream
+            st = _C.stream_ptr()
+            self._step_head(st)
+            self._eval_pen(self.pose_new, st)
+            self._step_tail(st)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_kernels(_C.stream_ptr())
-        self._graph = g
-        return g
+        g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0):
+            self._step_head(_C.stream_ptr())
+        self._eval_pen(self.pose_new, _C.stream_ptr())
+        with torch.cuda.graph(g1):
+            self._step_tail(_C.stream_ptr())
+        torch.cuda.synchronize()
+        for t, v in zip((self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema, self.step_count,
+                         self.terms), saved):
+            t.copy_(v)
+        self._graph = (g0, g1)
+        return self._graph

@@ -130,7 +130,29 @@ def farthest_point_sampling(points: np.ndarray, k: int, start: int = 0) -> np.nd
     return points[sel]
 
 
-def surface_points(face_verts: np.ndarray, num_samples: int = 2500, oversample: int = 20, seed: int = 42) -> np.ndarray:
-    """Dense area-weighted cloud -> FPS down to ``num_samples`` (object_model.py:163-178), float32."""
+def morton_order(points: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Permutation that sorts points along a 3-D Morton (Z-order) curve: neighbouring indices are spatial
+    neighbours, so the 64 points of a wavefront hit the same hand links (coherent culling in the E_pen kernel)."""
+    p = np.asarray(points, dtype=np.float64)
+    lo, hi = p.min(0), p.max(0)
+    q = ((p - lo) / np.maximum(hi - lo, 1e-12) * ((1 << bits) - 1)).astype(np.uint64)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(bits):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(code, kind="stable")
+
+
+def surface_points(face_verts: np.ndarray, num_samples: int = 2500, oversample: int = 20, seed: int = 42,
+                   sort: bool = True) -> np.ndarray:
+    """Dense area-weighted cloud -> FPS down to ``num_samples`` (object_model.py:163-178), float32, stored in
+    Morton order (the set of points is what matters to E_pen / cog, not their order)."""
     dense = sample_surface(face_verts, oversample * num_samples, seed)
-    return farthest_point_sampling(dense, num_samples).astype(np.float32)
+    pts = farthest_point_sampling(dense, num_samples)
+    if sort:
+        pts = pts[morton_order(pts)]
+    return pts.astype(np.float32)

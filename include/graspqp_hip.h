@@ -119,10 +119,13 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 
 /* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
  * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.
- * dis (B,P) = max over links of sqrt(d^2 + 1e-8) * (-sign); link (B,P) argmax; gvec (B,P,3) = d dis / d x_h. */
+ * dis (B,P) = max over links of sqrt(d^2 + 1e-8) * (-sign); link (B,P) argmax; gvec (B,P,3) = d dis / d x_h.
+ * penetration_only = 0: dis exact everywhere.  = 1: only links whose AABB contains the point are evaluated, so
+ * dis is exact where it is > 0 (all that E_pen uses, energy.py:59-61) and merely <= 0 elsewhere.           */
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
                         int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
-                        const float* link_T, float* dis, int32_t* link, float* gvec, void* stream);
+                        const float* link_T, int penetration_only, float* dis, int32_t* link, float* gvec,
+                        void* stream);
 int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                          const float* grad_dis /* (B,P) */, const int32_t* link, const float* gvec,

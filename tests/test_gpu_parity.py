@@ -275,6 +275,12 @@ def test_hand_penetration_and_self_penetration(gq):
     om.attach(hm)
     dis2 = hm.cal_distance(om.surface_points_tensor)
     assert torch.equal(dis2, dis)
+    # penetration-only mode (what E_pen uses): same values where dis > 0 (two template instantiations of one
+    # kernel: FMA contraction may differ in the last bit), non-positive elsewhere
+    dis3 = hm.cal_distance(om.surface_points_each, penetration_only=True)
+    pos = dis > 1e-6
+    torch.testing.assert_close(dis3[pos], dis[pos], rtol=1e-5, atol=1e-8)
+    assert (dis3[dis <= -1e-6] <= 0).all()
 
 
 # ---------------------------------------------------------------------------------------------------------------

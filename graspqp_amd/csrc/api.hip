@@ -30,4 +30,31 @@ int gq_device_check(int device, char* arch_out, int arch_len) {
   return GQ_OK;
 }
 
+// ---- gqTimer: a pair of HIP events that a launch fills with the kernel's own start / stop timestamps ----------
+int gq_timer_create(void** out) {
+  GQ_REQUIRE(out, "timer_create: null");
+  hipEvent_t* p = new hipEvent_t[2];
+  GQ_CHECK_HIP(hipEventCreate(&p[0]));
+  GQ_CHECK_HIP(hipEventCreate(&p[1]));
+  *out = p;
+  return GQ_OK;
+}
+
+int gq_timer_elapsed_ms(void* timer, float* ms) {  // synchronises on the stop event
+  GQ_REQUIRE(timer && ms, "timer_elapsed_ms: null");
+  hipEvent_t* p = (hipEvent_t*)timer;
+  GQ_CHECK_HIP(hipEventSynchronize(p[1]));
+  GQ_CHECK_HIP(hipEventElapsedTime(ms, p[0], p[1]));
+  return GQ_OK;
+}
+
+int gq_timer_destroy(void* timer) {
+  if (!timer) return GQ_OK;
+  hipEvent_t* p = (hipEvent_t*)timer;
+  (void)hipEventDestroy(p[0]);
+  (void)hipEventDestroy(p[1]);
+  delete[] p;
+  return GQ_OK;
+}
+
 }  // extern "C"

@@ -58,6 +58,53 @@ __device__ __forceinline__ float gq_wave_nanmin(float v) {
   return v;
 }
 
+// ---- DPP wave reductions (gfx9 row_shr / row_bcast network; result taken from lane 63, returned wave-uniform) ----
+// Same network as rocPRIM's warp_reduce_dpp: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shr:4, row_shr:8,
+// row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3).  Lanes that shift in nothing read 0; their partial results
+// never reach lane 63, so the network is valid for any associative op.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float gq_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double gq_dpp_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float gq_dpp_sum(float v) {
+  v += gq_dpp<0xb1, 0xf>(v);
+  v += gq_dpp<0x4e, 0xf>(v);
+  v += gq_dpp<0x114, 0xf>(v);
+  v += gq_dpp<0x118, 0xf>(v);
+  v += gq_dpp<0x142, 0xa>(v);
+  v += gq_dpp<0x143, 0xc>(v);
+  return gq_readlane(v, 63);
+}
+__device__ __forceinline__ double gq_dpp_sum_d(double v) {
+  v += gq_dpp_d<0xb1, 0xf>(v);
+  v += gq_dpp_d<0x4e, 0xf>(v);
+  v += gq_dpp_d<0x114, 0xf>(v);
+  v += gq_dpp_d<0x118, 0xf>(v);
+  v += gq_dpp_d<0x142, 0xa>(v);
+  v += gq_dpp_d<0x143, 0xc>(v);
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// NaN-propagating min over the wave (torch.min semantics)
+__device__ __forceinline__ float gq_dpp_nanmin(float v) {
+  v = gq_nanmin(v, gq_dpp<0xb1, 0xf>(v));
+  v = gq_nanmin(v, gq_dpp<0x4e, 0xf>(v));
+  v = gq_nanmin(v, gq_dpp<0x114, 0xf>(v));
+  v = gq_nanmin(v, gq_dpp<0x118, 0xf>(v));
+  v = gq_nanmin(v, gq_dpp<0x142, 0xa>(v));
+  v = gq_nanmin(v, gq_dpp<0x143, 0xc>(v));
+  return gq_readlane(v, 63);
+}
+
 // ---- small vector math --------------------------------------------------------------------------------
 struct gq3 {
   float x, y, z;

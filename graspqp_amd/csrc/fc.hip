@@ -121,9 +121,9 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
     }
   }
 #pragma unroll
-  for (int a = 0; a < 6; ++a) r[a] = gq_wave_sum(r[a]);
+  for (int a = 0; a < 6; ++a) r[a] = gq_dpp_sum(r[a]);
 #pragma unroll
-  for (int i = 0; i < 21; ++i) gr[i] = gq_wave_sum_d(gr[i]);
+  for (int i = 0; i < 21; ++i) gr[i] = gq_dpp_sum_d(gr[i]);
   double Lm[21];
   const bool ok = gq_chol6(gr, Lm);
   double lp = 1.0;
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
-    r[a] = gq_wave_sum(r[a]);
-    fd[a] = gq_wave_sum(fd[a]);
+    r[a] = gq_dpp_sum(r[a]);
+    fd[a] = gq_dpp_sum(fd[a]);
   }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) gr[i] = gq_wave_sum_d(gr[i]);
+  for (int i = 0; i < 21; ++i) gr[i] = gq_dpp_sum_d(gr[i]);
   double Lm[21];
   const bool ok = gq_chol6(gr, Lm);
   const float ge = g.g_e[row], svd = g.svd[row], val = g.val[row];

@@ -88,13 +88,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_select_kernel(const float* __re
       bi = it;
     }
   }
-  if (lane < nz) {
-    const float* s = snap + (((size_t)row * max_iter + bi) * 5) * nz + lane;
-    x[(size_t)row * nz + lane] = s[0];
-    lam[(size_t)row * 2 * nz + lane] = s[nz];
-    lam[(size_t)row * 2 * nz + nz + lane] = s[2 * nz];
-    slack[(size_t)row * 2 * nz + lane] = s[3 * nz];
-    slack[(size_t)row * 2 * nz + nz + lane] = s[4 * nz];
+  for (int k = lane; k < nz; k += GQ_WAVE) {
+    const float* s = snap + (((size_t)row * max_iter + bi) * 5) * nz + k;
+    x[(size_t)row * nz + k] = s[0];
+    lam[(size_t)row * 2 * nz + k] = s[nz];
+    lam[(size_t)row * 2 * nz + nz + k] = s[2 * nz];
+    slack[(size_t)row * 2 * nz + k] = s[3 * nz];
+    slack[(size_t)row * 2 * nz + nz + k] = s[4 * nz];
   }
   if (lane == 0 && best_iter) best_iter[row] = bi;
 }
@@ -126,12 +126,14 @@ static GqQpWs gq_qp_carve(void* base, int B, int nz, int max_iter) {
 }
 
 static int gq_launch_iter(const GqQpArgs& a, int mode, hipStream_t st) {
+  if (mode == 0) return gq_qp_lr_launch_iter(a, st);
   if (a.nz <= 16) return gq_qp_launch_iter_16(a, mode, st);
   if (a.nz <= 32) return gq_qp_launch_iter_32(a, mode, st);
   if (a.nz <= 48) return gq_qp_launch_iter_48(a, mode, st);
   return gq_qp_launch_iter_64(a, mode, st);
 }
 static int gq_launch_bwd(const GqQpBwdArgs& a, int mode, hipStream_t st) {
+  if (mode == 0) return gq_qp_lr_launch_bwd(a, st);
   if (a.nz <= 16) return gq_qp_launch_bwd_16(a, mode, st);
   if (a.nz <= 32) return gq_qp_launch_bwd_32(a, mode, st);
   if (a.nz <= 48) return gq_qp_launch_bwd_48(a, mode, st);
@@ -141,7 +143,7 @@ static int gq_launch_bwd(const GqQpBwdArgs& a, int mode, hipStream_t st) {
 static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, float* x, float* lam, float* slack,
                                 int* best_iter, int* n_iter, void* ws, size_t ws_bytes, hipStream_t st, int mode) {
   GQ_REQUIRE(a.B > 0 && a.nz > 0, "boxqp: empty batch (B=%d nz=%d)", a.B, a.nz);
-  GQ_REQUIRE(a.nz <= 64, "boxqp: nz=%d > 64 is not supported by this build (one row per lane)", a.nz);
+  GQ_REQUIRE(a.nz <= (mode == 0 ? 128 : 64), "boxqp: nz=%d exceeds the supported size (%d)", a.nz, mode == 0 ? 128 : 64);
   GQ_REQUIRE(a.max_iter >= 1 && a.max_iter <= 64, "boxqp: max_iter=%d out of range", a.max_iter);
   GQ_REQUIRE(mode == 1 || (a.m >= 1 && a.m <= 8), "boxqp: m=%d must be in [1,8]", a.m);
   GQ_REQUIRE(x && lam && slack && ws, "boxqp: null output/workspace pointer");
@@ -214,7 +216,7 @@ int gq_boxqp_forward(const float* Q, const float* p, const float* lower, const f
 int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, const float* grad_x, int64_t batch,
                           int m, int nz, float ridge, float* dx, float* dlam, void* stream) {
   GQ_REQUIRE(A && lam && slack && grad_x && dx && dlam, "lsq_boxqp_backward: null pointer");
-  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 64 && m >= 1 && m <= 8, "lsq_boxqp_backward: bad sizes B=%lld m=%d nz=%d",
+  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 128 && m >= 1 && m <= 8, "lsq_boxqp_backward: bad sizes B=%lld m=%d nz=%d",
              (long long)batch, m, nz);
   GqQpBwdArgs a{};
   a.A = A;

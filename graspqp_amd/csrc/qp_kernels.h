@@ -56,12 +56,12 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_iter_kernel(GqQpArgs g) {
   float x, su, sl, zu, zl;
   gq_kkt_solve<NZ>(a, dinv, lane, 1.0f, 1.0f, p, 0.0f, 0.0f, -hu, -hl, x, su, sl, zu, zl);
   {
-    float ms = gq_wave_nanmin(live ? gq_nanmin(su, sl) : GQ_INF);
+    float ms = gq_dpp_nanmin(live ? gq_nanmin(su, sl) : GQ_INF);
     if (ms < 0.0f) {
       su = su - ms + 1.0f;
       sl = sl - ms + 1.0f;
     }
-    float mz = gq_wave_nanmin(live ? gq_nanmin(zu, zl) : GQ_INF);
+    float mz = gq_dpp_nanmin(live ? gq_nanmin(zu, zl) : GQ_INF);
     if (mz < 0.0f) {
       zu = zu - mz + 1.0f;
       zl = zl - mz + 1.0f;
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_iter_kernel(GqQpArgs g) {
     const float rx = (zu - zl) + Qx + p;
     const float rzu = x + su - hu;
     const float rzl = -x + sl - hl;
-    const float sz = gq_wave_sum(live ? (su * zu + sl * zl) : 0.0f);
+    const float sz = gq_dpp_sum(live ? (su * zu + sl * zl) : 0.0f);
     const float mu = fabsf(sz / m2);
-    const float nrz = sqrtf(gq_wave_sum(live ? (rzu * rzu + rzl * rzl) : 0.0f));
-    const float nrx = sqrtf(gq_wave_sum(live ? rx * rx : 0.0f));
+    const float nrz = sqrtf(gq_dpp_sum(live ? (rzu * rzu + rzl * rzl) : 0.0f));
+    const float nrx = sqrtf(gq_dpp_sum(live ? rx * rx : 0.0f));
     const float resid = nrz + nrx + m2 * mu;
     const bool record = (it == 0) || (resid < best);  // false for NaN: a NaN iterate never becomes best
     if (record) {
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_iter_kernel(GqQpArgs g) {
     gq_kkt_solve<NZ>(a, dinv, lane, du, dl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
     float st = gq_nanmin(gq_nanmin(gq_step_ratio(zu, dzua), gq_step_ratio(zl, dzla)),
                          gq_nanmin(gq_step_ratio(su, dsua), gq_step_ratio(sl, dsla)));
-    float alpha = gq_nanmin(gq_wave_nanmin(live ? st : GQ_INF), 1.0f);
-    const float t3 = gq_wave_sum(
+    float alpha = gq_nanmin(gq_dpp_nanmin(live ? st : GQ_INF), 1.0f);
+    const float t3 = gq_dpp_sum(
         live ? ((su + alpha * dsua) * (zu + alpha * dzua) + (sl + alpha * dsla) * (zl + alpha * dzla)) : 0.0f);
     float sig = t3 / sz;
     sig = sig * sig * sig;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_iter_kernel(GqQpArgs g) {
     const float dx = dxa + dxc, dsu = dsua + dsuc, dsl = dsla + dslc, dzu = dzua + dzuc, dzl = dzla + dzlc;
     st = gq_nanmin(gq_nanmin(gq_step_ratio(zu, dzu), gq_step_ratio(zl, dzl)),
                    gq_nanmin(gq_step_ratio(su, dsu), gq_step_ratio(sl, dsl)));
-    alpha = gq_nanmin(0.999f * gq_wave_nanmin(live ? st : GQ_INF), 1.0f);
+    alpha = gq_nanmin(0.999f * gq_dpp_nanmin(live ? st : GQ_INF), 1.0f);
     if (live) {
       x += alpha * dx;
       su += alpha * dsu;
@@ -196,16 +196,17 @@ GQ_DECL_QP_NZ(32)
 GQ_DECL_QP_NZ(48)
 GQ_DECL_QP_NZ(64)
 
+// only the dense-Q form (mode 1) uses these register-Cholesky kernels; the A'A form goes through qp_lr.hip
 #define GQ_DEFINE_QP_NZ(NZ)                                                                                   \
   int gq_qp_launch_iter_##NZ(const GqQpArgs& a, int mode, hipStream_t st) {                                    \
-    if (mode == 0) hipLaunchKernelGGL((gq_qp_iter_kernel<NZ, 0>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);         \
-    else hipLaunchKernelGGL((gq_qp_iter_kernel<NZ, 1>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);                   \
+    hipLaunchKernelGGL((gq_qp_iter_kernel<NZ, 1>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);                        \
     GQ_LAUNCH_CHECK();                                                                                         \
     return GQ_OK;                                                                                              \
   }                                                                                                            \
   int gq_qp_launch_bwd_##NZ(const GqQpBwdArgs& a, int mode, hipStream_t st) {                                  \
-    if (mode == 0) hipLaunchKernelGGL((gq_qp_bwd_kernel<NZ, 0>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);          \
-    else hipLaunchKernelGGL((gq_qp_bwd_kernel<NZ, 1>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);                    \
+    hipLaunchKernelGGL((gq_qp_bwd_kernel<NZ, 1>), dim3(a.B), dim3(GQ_WAVE), 0, st, a);                         \
     GQ_LAUNCH_CHECK();                                                                                         \
     return GQ_OK;                                                                                              \
   }
+int gq_qp_lr_launch_iter(const GqQpArgs& a, hipStream_t st);
+int gq_qp_lr_launch_bwd(const GqQpBwdArgs& a, hipStream_t st);

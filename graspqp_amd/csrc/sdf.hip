@@ -9,6 +9,7 @@
 //     lane owns one point; the face records are wave-uniform so they travel through the scalar cache / SGPRs
 //     and the per-lane work is pure FP32 VALU.
 #include "tri.h"
+#include <hip/hip_ext.h>
 
 // rec[i] = record of face perm[i] (perm == nullptr: identity)
 __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t* __restrict__ perm,
@@ -580,7 +581,7 @@ int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float*
 // Fused hand-penetration query (HandModel.cal_distance, hand_model.py:875-987).
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                         int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
-                        int penetration_only, float* dis, int32_t* link, float* gvec, void* stream) {
+                        int penetration_only, float* dis, int32_t* link, float* gvec, void* timer, void* stream) {
   GQ_REQUIRE(links && surface_points && hand_pose && Rg && link_T && dis && link && gvec, "hand_pen_forward: null");
   GQ_REQUIRE(n_obj > 0 && n_surface > 0 && batch_each > 0 && pose_dim >= 9, "hand_pen_forward: bad sizes");
   GqPenArgs a{};
@@ -603,8 +604,15 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   a.gvec = gvec;
   GQ_REQUIRE(a.B <= 65535, "hand_pen_forward: B=%d exceeds grid.y limit", a.B);
   const dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)a.B);
-  if (penetration_only) hipLaunchKernelGGL(gq_hand_pen_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(gq_hand_pen_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timer) {  // gqTimer: the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), not stream markers
+    e0 = ((hipEvent_t*)timer)[0];
+    e1 = ((hipEvent_t*)timer)[1];
+  }
+  if (penetration_only)
+    hipExtLaunchKernelGGL(gq_hand_pen_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  else
+    hipExtLaunchKernelGGL(gq_hand_pen_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -409,7 +409,7 @@ class _HandPen(torch.autograd.Function):
         link = torch.empty(B, P, dtype=torch.int32, device=dev)
         gvec = torch.empty(B, P, 3, device=dev)
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
-                _C.f32(Rg), _C.f32(LT), int(bool(penetration_only)), _C.f32(dis), _C.i32(link), _C.f32(gvec),
+                _C.f32(Rg), _C.f32(LT), int(bool(penetration_only)), _C.f32(dis), _C.i32(link), _C.f32(gvec), None,
                 _C.stream_ptr())
         ctx.save_for_backward(hp, sp, idx, Rg, LT, ws, link, gvec)
         ctx.hand, ctx.batch_each, ctx.nb = hand, int(batch_each), nb

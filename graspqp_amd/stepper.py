@@ -103,11 +103,12 @@ class GraspStepper:
           float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
           _C.ptr(self.fc_ws), self.fc_nb, st)
 
-    def _eval_pen(self, pose, st):
-        """The dominant kernel, kept as a launch of its own so bench.py can bracket it with HIP events."""
+    def _eval_pen(self, pose, st, timer=None):
+        """The dominant kernel, kept as a launch of its own so bench.py can time it (gqTimer = HIP events filled with
+        the kernel's own start/stop timestamps by hipExtLaunchKernelGGL)."""
         _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
                 _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
-                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec), st)
+                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec), timer, st)
 
     def _eval_post(self, pose, idx, st):
         B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
@@ -135,14 +136,7 @@ class GraspStepper:
 
     def _evaluate(self, pose, idx, st):
         self._eval_pre(pose, idx, st)
-        ev = self.kernel_events
-        if ev is not None:  # bench.py: HIP events around the dominant kernel, on the stream it is launched on
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         self._eval_pen(pose, st)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
         self._eval_post(pose, idx, st)
 
     def evaluate(self, pose, idx):
@@ -192,13 +186,24 @@ class GraspStepper:
 
     def _pen_timed(self, st):
         ev = self.kernel_events
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        self._eval_pen(self.pose_new, st)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
+        if ev is None:
+            self._eval_pen(self.pose_new, st)
+            return
+        t = ctypes.c_void_p(0)
+        _C.call("gq_timer_create", ctypes.byref(t))
+        self._eval_pen(self.pose_new, st, t)
+        ev.append(t)
+
+    def kernel_times_ms(self):
+        """Durations (ms) of the timed hand-penetration launches collected since ``kernel_events = []``."""
+        out = []
+        for t in self.kernel_events or []:
+            ms = ctypes.c_float(0)
+            _C.call("gq_timer_elapsed_ms", t, ctypes.byref(ms))
+            _C.call("gq_timer_destroy", t)
+            out.append(float(ms.value))
+        self.kernel_events = None
+        return out
 
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""

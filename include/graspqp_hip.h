@@ -25,6 +25,10 @@ extern "C" {
 int gq_version(void);
 const char* gq_last_error(void);
 int gq_device_check(int device, char* arch_out, int arch_len);
+/* gqTimer: event pair that a launch taking a `timer` argument fills with the kernel's own start/stop timestamps */
+int gq_timer_create(void** out);
+int gq_timer_elapsed_ms(void* timer, float* ms);
+int gq_timer_destroy(void* timer);
 
 /* ---- mesh signed distance: torchsdf.compute_sdf / index_vertices_by_faces ------------------------
  * reference call sites: core/object_model.py:147,220  core/hand_model.py:352,953
@@ -48,7 +52,7 @@ int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float*
 /* ---- box-constrained QP: qpth.qp.QPFunction as used by SQPLsqSolver.solve --------------------------
  * reference: metrics/solver/qp_solver.py:8,60-134 (QPFunction(maxIter=12, eps=5e-2), G = [I;-I], h = [u;-l]).
  * lam / slack are (B, 2 nz): upper-bound block then lower-bound block.  lower/upper may be NULL (scalars used).
- * gq_lsq_*: Q = A'A + ridge I, p = -A'b with A (B,m,nz), m <= 8, b (B,m) or NULL (= 0).  nz <= 64.          */
+ * gq_lsq_*: Q = A'A + ridge I, p = -A'b with A (B,m,nz), m <= 8, b (B,m) or NULL (= 0); nz <= 128 (dense Q: <= 64).         */
 int gq_boxqp_workspace_bytes(int64_t batch, int nz, int max_iter, size_t* bytes);
 int gq_boxqp_forward(const float* Q /* (B,nz,nz) */, const float* p /* (B,nz) or NULL */, const float* lower,
                      const float* upper, float lower_s, float upper_s, int64_t batch, int nz, float eps, int max_iter,
@@ -125,7 +129,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
                         int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                         const float* link_T, int penetration_only, float* dis, int32_t* link, float* gvec,
-                        void* stream);
+                        void* timer /* gqTimer or NULL */, void* stream);
 int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                          const float* grad_dis /* (B,P) */, const int32_t* link, const float* gvec,

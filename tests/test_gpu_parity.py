@@ -127,7 +127,7 @@ def test_qp_reference_known_answer(gq, golden_dir):
     assert torch.allclose(sol, torch.zeros_like(sol), atol=1e-4)
 
 
-@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4)])
+@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4), (12, 8)])
 def test_qp_iterate_matches_oracle(gq, golden_dir, n, k):
     g = _load(golden_dir, f"span_n{n}_k{k}.npz")
     F = torch.tensor(g["F"], dtype=torch.float64)
@@ -168,7 +168,7 @@ def test_qpfunction_level_boundary(gq):
         QPFunction()(Q.float().cuda(), p.float().cuda(), (2 * G).float().cuda(), h.float().cuda())
 
 
-@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4)])
+@pytest.mark.parametrize("n,k", [(4, 4), (12, 4), (16, 4), (12, 8)])
 def test_fc_energy_and_gradient(gq, golden_dir, n, k):
     g = _load(golden_dir, f"span_n{n}_k{k}.npz")
     pts = torch.tensor(g["contact_pts"], dtype=torch.float64)

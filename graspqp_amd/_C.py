@@ -24,6 +24,7 @@ _SCALARS = {
     "int64_t": ctypes.c_int64,
     "float": ctypes.c_float,
     "size_t": ctypes.c_size_t,
+    "uint64_t": ctypes.c_uint64,
 }
 
 

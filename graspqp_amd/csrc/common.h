@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "../../include/graspqp_hip.h"  // every definition is checked against the published prototypes
+
 #define GQ_WAVE 64
 #define GQ_INF_F __builtin_inff()
 

@@ -5,13 +5,6 @@
 // constants for autograd, object_model.py:246).
 #include "common.h"
 
-extern "C" int gq_lsq_boxqp_forward(const float*, const float*, const float*, const float*, float, float, int64_t, int,
-                                    int, float, float, int, int, float*, float*, float*, int32_t*, int32_t*, void*,
-                                    size_t, void*);
-extern "C" int gq_lsq_boxqp_backward(const float*, const float*, const float*, const float*, int64_t, int, int, float,
-                                     float*, float*, void*);
-extern "C" int gq_boxqp_workspace_bytes(int64_t, int, int, size_t*);
-
 struct GqCone {
   gq3 f;    // cone edge (already divided by k)
   gq3 tau;  // torque_weight * (r x f)

@@ -291,15 +291,19 @@ __global__ __launch_bounds__(64) void gq_fk_backward_kernel(GqFkBwdArgs g) {
 }
 
 // ---- self penetration (hand_model.py:989-1040) ----------------------------------------------------------------------
+// block = 64 threads = 4 rows x 16 lanes; lane (row, q) scans sphere groups q, q+16, ... (a group = the spheres of
+// one link), finds each group's most penetrating pair against all LATER groups, then lane q == 0 folds the groups
+// in order (bitwise reproducible) into the energy and the centre gradients.
 __global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* __restrict__ centers, int B,
                                                          float* __restrict__ e_spen, float* __restrict__ g_centers) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= B) return;
-  const float* c = centers + (size_t)row * h.S * 3;
-  float* gc = g_centers + (size_t)row * h.S * 3;
-  for (int i = 0; i < h.S * 3; ++i) gc[i] = 0.0f;
-  float e = 0.0f;
-  for (int gi = 0; gi + 1 < h.NG; ++gi) {
+  __shared__ float s_pen[4][64];
+  __shared__ int s_a[4][64], s_b[4][64];
+  const int r4 = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int row = blockIdx.x * 4 + r4;
+  const bool ok = row < B;
+  const float* c = centers + (size_t)(ok ? row : 0) * h.S * 3;
+  const int ng = h.NG - 1;  // the last group has nothing after it
+  for (int gi = q; gi < ng && gi < 64; gi += 16) {
     const int a0 = h.group_off[gi], a1 = h.group_off[gi + 1];
     float best = GQ_INF_F;
     int ba = -1, bb = -1;
@@ -316,6 +320,20 @@ __global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* 
         }
       }
     }
+    s_pen[r4][gi] = best;
+    s_a[r4][gi] = ba;
+    s_b[r4][gi] = bb;
+  }
+  __syncthreads();
+  if (!ok) return;
+  float* gc = g_centers + (size_t)row * h.S * 3;
+  for (int i = q; i < h.S * 3; i += 16) gc[i] = 0.0f;
+  __syncthreads();
+  if (q != 0) return;
+  float e = 0.0f;
+  for (int gi = 0; gi < ng && gi < 64; ++gi) {
+    const float best = s_pen[r4][gi];
+    const int ba = s_a[r4][gi], bb = s_b[r4][gi];
     if (best < 0.0f && ba >= 0) {
       e -= best;
       const gq3 d = gq_mk(c[ba * 3] - c[bb * 3] + 1e-13f, c[ba * 3 + 1] - c[bb * 3 + 1] + 1e-13f,
@@ -330,23 +348,6 @@ __global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-struct gqHandDesc {
-  int32_t n_dofs, n_links, n_cand, n_spheres;
-  const int32_t* node_parent;
-  const int32_t* node_type;
-  const float* node_pre;     // (J, 12)
-  const float* node_axis;    // (J, 3)
-  const int32_t* link_node;  // (L)
-  const float* link_offset;  // (L, 12)
-  const float* cand_pos;     // (C, 3)
-  const float* cand_nrm;     // (C, 3)
-  const int32_t* cand_link;  // (C)
-  const float* sphere;       // (S, 4)
-  const int32_t* sphere_link;  // (S), non-decreasing
-  const float* joints_lower;   // (J)
-  const float* joints_upper;   // (J)
-};
-
 template <typename T>
 static int gq_upload(T** dst, const T* src, size_t n) {
   *dst = nullptr;
@@ -379,7 +380,7 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
   h->S = d->n_spheres;
   int32_t groups[258];
   int ng = 0;
-  for (int s = 0; s < d->n_spheres && ng < 256; ++s)
+  for (int s = 0; s < d->n_spheres && ng < 64; ++s)
     if (s == 0 || d->sphere_link[s] != d->sphere_link[s - 1]) groups[ng++] = s;
   groups[ng] = d->n_spheres;
   h->NG = ng;
@@ -479,7 +480,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 int gq_self_pen_forward(const gqHand* h, const float* sphere_centers, int64_t batch, float* e_spen, float* g_centers,
                         void* stream) {
   GQ_REQUIRE(h && sphere_centers && e_spen && g_centers && batch > 0, "self_pen_forward: bad arguments");
-  hipLaunchKernelGGL(gq_self_pen_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *h,
+  hipLaunchKernelGGL(gq_self_pen_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, (hipStream_t)stream, *h,
                      sphere_centers, (int)batch, e_spen, g_centers);
   GQ_LAUNCH_CHECK();
   return GQ_OK;

@@ -188,34 +188,44 @@ struct GqProposeArgs {
   float* s_out;     // (B) or null
 };
 
-__global__ __launch_bounds__(64) void gq_mala_propose_kernel(GqProposeArgs g) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.B) return;
+// one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
+__global__ __launch_bounds__(GQ_WAVE) void gq_mala_propose_kernel(GqProposeArgs g) {
+  const int row = blockIdx.x, lane = gq_lane();
   const int64_t st = g.step[row];
   const float s = g.step_size * powf(g.decay, (float)(st / g.stepsize_period));
-  bool any_nan = false;
-  for (int d = 0; d < g.D; ++d) {
-    const size_t o = (size_t)row * g.D + d;
-    float gr = g.grad[o];
-    if (g.clip) {
-      gr = fminf(fmaxf(gr, -100.0f), 100.0f);
-      if (gr != gr) gr = 0.0f;
+  float v[2] = {0.0f, 0.0f};
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = lane + GQ_WAVE * c;
+    if (d < g.D) {
+      const size_t o = (size_t)row * g.D + d;
+      float gr = g.grad[o];
+      if (g.clip) {
+        gr = fminf(fmaxf(gr, -100.0f), 100.0f);
+        if (gr != gr) gr = 0.0f;
+      }
+      float em = g.mu * g.g2[d] + (1.0f - g.mu) * g.ema[o];
+      if (em != em) em = 0.0f;
+      g.ema[o] = em;
+      v[c] = g.hand_pose[o] - s * gr / (sqrtf(em) + 1e-6f);
+      bad |= (v[c] != v[c]);
     }
-    float em = g.mu * g.g2[d] + (1.0f - g.mu) * g.ema[o];
-    if (em != em) em = 0.0f;
-    g.ema[o] = em;
-    const float v = g.hand_pose[o] - s * gr / (sqrtf(em) + 1e-6f);
-    any_nan |= (v != v);
-    g.pose_out[o] = v;
   }
-  if (any_nan)
-    for (int d = 0; d < g.D; ++d) g.pose_out[(size_t)row * g.D + d] = 0.0f;
-  for (int c = 0; c < g.n; ++c) {
+  const bool zero_row = __ballot(bad) != 0ull;  // optimizer.py:242-244: a row with any NaN is zeroed
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = lane + GQ_WAVE * c;
+    if (d < g.D) g.pose_out[(size_t)row * g.D + d] = zero_row ? 0.0f : v[c];
+  }
+  for (int c = lane; c < g.n; c += GQ_WAVE) {
     const size_t o = (size_t)row * g.n + c;
     g.idx_out[o] = (g.u_switch[o] < g.switch_p) ? g.new_idx[o] : g.idx[o];
   }
-  g.step[row] = st + 1;
-  if (g.s_out) g.s_out[row] = s;
+  if (lane == 0) {
+    g.step[row] = st + 1;
+    if (g.s_out) g.s_out[row] = s;
+  }
 }
 
 // z = (E - mean_obj) / std_obj (unbiased), one block per object
@@ -275,9 +285,8 @@ struct GqAcceptArgs {
   float* terms;            // (n_terms,B) or null
 };
 
-__global__ __launch_bounds__(64) void gq_mala_accept_kernel(GqAcceptArgs g) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.B) return;
+__global__ __launch_bounds__(GQ_WAVE) void gq_mala_accept_kernel(GqAcceptArgs g) {
+  const int row = blockIdx.x, lane = gq_lane();
   float T = g.T0 * powf(g.decay, (float)(g.step[row] / g.annealing_period));
   if (g.z) {
     const float proba = 0.5f * (1.0f + erff(g.z[row] * 0.70710678118654752f));
@@ -286,17 +295,19 @@ __global__ __launch_bounds__(64) void gq_mala_accept_kernel(GqAcceptArgs g) {
   const float e_old = g.energy[row], e_new = g.new_energy[row];
   bool acc = g.u_accept[row] < expf((e_old - e_new) / T);
   if (g.reset_mask && g.reset_mask[row]) acc = true;
-  g.accept[row] = acc ? 1 : 0;
-  if (g.temperature) g.temperature[row] = T;
-  if (acc) {
-    g.energy[row] = e_new;
-    for (int d = 0; d < g.D; ++d) {
+  if (lane == 0) {
+    g.accept[row] = acc ? 1 : 0;
+    if (g.temperature) g.temperature[row] = T;
+    if (acc) g.energy[row] = e_new;
+  }
+  if (acc) {  // wave-uniform
+    for (int d = lane; d < g.D; d += GQ_WAVE) {
       const size_t o = (size_t)row * g.D + d;
       g.pose[o] = g.pose_new[o];
       g.grad[o] = g.grad_new[o];
     }
-    for (int c = 0; c < g.n; ++c) g.idx[(size_t)row * g.n + c] = g.idx_new[(size_t)row * g.n + c];
-    for (int t = 0; t < g.n_terms; ++t) g.terms[(size_t)t * g.B + row] = g.terms_new[(size_t)t * g.B + row];
+    for (int c = lane; c < g.n; c += GQ_WAVE) g.idx[(size_t)row * g.n + c] = g.idx_new[(size_t)row * g.n + c];
+    for (int t = lane; t < g.n_terms; t += GQ_WAVE) g.terms[(size_t)t * g.B + row] = g.terms_new[(size_t)t * g.B + row];
   }
 }
 
@@ -399,7 +410,7 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
                     int64_t* step, float* pose_out, int64_t* idx_out, float* step_size_out, float* g2_scratch,
                     void* stream) {
   GQ_REQUIRE(hand_pose && grad && contact_idx && u_switch && new_idx && ema && step && pose_out && idx_out &&
-                 g2_scratch && batch > 0 && pose_dim > 9 && n_contact > 0 && stepsize_period > 0,
+                 g2_scratch && batch > 0 && pose_dim > 9 && pose_dim <= 128 && n_contact > 0 && stepsize_period > 0,
              "mala_propose: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gq_colsq_mean_kernel, dim3((unsigned)pose_dim), dim3(256), 0, st, grad, (int)batch, pose_dim,
@@ -426,7 +437,7 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
   a.pose_out = pose_out;
   a.idx_out = idx_out;
   a.s_out = step_size_out;
-  hipLaunchKernelGGL(gq_mala_propose_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(gq_mala_propose_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, st, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }
@@ -473,7 +484,7 @@ int gq_mala_accept(const float* new_energy, const float* u_accept, const float* 
   a.n_terms = n_terms;
   a.terms_new = terms_new;
   a.terms = terms;
-  hipLaunchKernelGGL(gq_mala_accept_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gq_mala_accept_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

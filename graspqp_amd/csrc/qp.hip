@@ -70,6 +70,46 @@ __global__ __launch_bounds__(256) void gq_qp_stop_kernel(const float* __restrict
   }
 }
 
+// same rule, one wavefront, DPP reductions instead of block barriers (used for B <= 8192)
+__global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* __restrict__ resid,
+                                                                  const float* __restrict__ mu, int B, int max_iter,
+                                                                  float eps, int not_improved_lim,
+                                                                  float* __restrict__ runmin, int* __restrict__ kstar) {
+  const int lane = gq_lane();
+  int not_improved = 0;
+  int stop_at = max_iter - 1;
+  for (int it = 0; it < max_iter; ++it) {
+    float mx = -GQ_INF, mn = GQ_INF;
+    bool any = false;
+    for (int r = lane; r < B; r += GQ_WAVE) {
+      const float rs = resid[(size_t)r * max_iter + it];
+      float bst = rs;
+      if (it > 0) {
+        bst = runmin[r];
+        if (rs < bst) {
+          bst = rs;
+          any = true;
+        }
+      }
+      runmin[r] = bst;
+      mx = gq_nanmax(mx, bst);
+      mn = gq_nanmin(mn, mu[(size_t)r * max_iter + it]);
+    }
+    const bool any_w = __ballot(any) != 0ull;
+    const float mxw = -gq_dpp_nanmin(-mx);  // NaN-propagating max
+    const float mnw = gq_dpp_nanmin(mn);
+    not_improved = (it == 0) ? 0 : (any_w ? 0 : not_improved + 1);
+    if ((not_improved == not_improved_lim) || (mxw < eps) || (mnw > 1e32f)) {
+      stop_at = it;
+      break;
+    }
+  }
+  if (lane == 0) {
+    kstar[0] = stop_at;
+    kstar[1] = stop_at + 1;
+  }
+}
+
 __global__ __launch_bounds__(GQ_WAVE) void gq_qp_select_kernel(const float* __restrict__ resid,
                                                                const float* __restrict__ snap,
                                                                const int* __restrict__ kstar, int B, int nz,
@@ -154,8 +194,12 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
   a.snap = w.snap;
   int rc = gq_launch_iter(a, mode, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
-                     not_improved_lim, w.runmin, w.kstar);
+  if (a.B <= 8192)
+    hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
+                       not_improved_lim, w.runmin, w.kstar);
+  else
+    hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
+                       not_improved_lim, w.runmin, w.kstar);
   GQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(gq_qp_select_kernel, dim3(a.B), dim3(GQ_WAVE), 0, st, w.resid, w.snap, w.kstar, a.B, a.nz,
                      a.max_iter, x, lam, slack, best_iter);

@@ -195,21 +195,39 @@ struct GqPenArgs {
   const float* aabb;   // (L,8) lo.xyz,-,hi.xyz,-
   const float* sub_aabb;   // (n_sub,8) boxes of the 16-face sub-clusters (faces Morton-sorted per link)
   const int32_t* sub_off;  // (L+1)
+  const float* occ_invz;   // (L) 32 / z-extent of the link AABB (x, y scales ride in the pads of aabb)
+  const uint32_t* occ;     // (L, 32*32) words: bit ix of word iz*32+iy set <=> voxel may contain interior/surface
   int B, P, L, D, batch_each;
   float* dis;     // (B, P)
   int32_t* link;  // (B, P)
   float* gvec;    // (B, P, 3)
+  uint64_t* span;  // optional [min start, max end] of the launch in 100 MHz s_memrealtime ticks
+  unsigned long long* dbg;  // optional counters: [0] needing (point,link) pairs, [1] (wave,link) evaluations,
+                            // [2] (wave,sub-cluster) evaluations, [3] waves
 };
+
+// launch time span in 100 MHz s_memrealtime ticks, sharded 64 ways so the atomics of 1e3 blocks do not pile up on one
+// address: span[2*s] = min start, span[2*s+1] = max end of the blocks with (linear block id % 64) == s
+__device__ __forceinline__ void gq_span_open(uint64_t* span) {
+  const unsigned s = (blockIdx.x + blockIdx.y * gridDim.x) & 63u;
+  atomicMin((unsigned long long*)&span[2 * s], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void gq_span_close(uint64_t* span) {
+  const unsigned s = (blockIdx.x + blockIdx.y * gridDim.x) & 63u;
+  atomicMax((unsigned long long*)&span[2 * s + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 
 // MODE 0 ("exact"): dis is the exact max over links for every point.  A link is skipped for a whole wavefront
 //   only when, for every lane, its AABB lower bound already proves dis_l <= best (points outside a link's AABB
 //   are outside the link, so dis_l = -sqrt(d_l^2+1e-8) <= -sqrt(lb^2+1e-8)).
 // MODE 1 ("penetration only"): what E_pen needs (energy.py:59-61 zeroes dis <= 0): a link is evaluated only if
-//   some lane's point lies inside its AABB; dis is exact wherever it is > 0 and merely <= 0 elsewhere.
+//   some lane's point lies in a voxel of the link's 32^3 occupancy grid that touches the surface or the interior;
+//   dis is exact wherever it is > 0 and merely <= 0 elsewhere.  MODE 2: the same with the AABB test only.
 template <int MODE>
 __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
   const int row = blockIdx.y;
   const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.span && threadIdx.x == 0) gq_span_open(g.span);
   const bool ok = pt < g.P;
   const int obj = row / g.batch_each;
   const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
@@ -229,13 +247,29 @@ __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
     const gq3 xl = gq_mtv(Rl, xh - tl);
     const float lb2 = gq_aabb_dist2(g.aabb + l * 8, xl);  // squared distance to the link's AABB
     bool need;
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 2) {
       need = ok && (lb2 <= 0.0f);
+      if (MODE == 1 && need && g.occ) {
+        // 32^3 occupancy grid over the link's AABB: a point in a voxel that neither touches the surface nor lies
+        // inside the mesh is outside -> this link cannot be penetrated by it
+        const float* bb = g.aabb + l * 8;
+        const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7];  // bb[3], bb[7]: 32/extent x, y
+        const float uz = (xl.z - bb[2]) * g.occ_invz[l];
+        const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
+        need = (g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u;
+      }
     } else {
       // can link l still beat best_dis?  only if it may be penetrated (inside AABB) or closer than the best so far
       need = ok && ((lb2 <= 0.0f) || (best_dis < 0.0f && fmaf(lb2, 0.9999f, 1e-8f) < best_dis * best_dis));
     }
     if (__ballot(need) == 0ull) continue;  // wave-uniform skip
+    if (g.dbg) {
+      const unsigned long long nm = __ballot(need);
+      if (gq_lane() == 0) {
+        atomicAdd(&g.dbg[0], (unsigned long long)__popcll(nm));
+        atomicAdd(&g.dbg[1], 1ull);
+      }
+    }
     // exact nearest face of link l for the lanes that need it: visit 16-face sub-clusters, skipping (for the whole
     // wave) those whose box is farther than every needing lane's running minimum
     float bd = GQ_INF_F;
@@ -245,6 +279,7 @@ __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
     for (int sc = s0; sc < s1; ++sc) {
       const float lbs = gq_aabb_dist2(g.sub_aabb + (size_t)sc * 8, xl);
       if (__ballot(need && lbs * 0.9999f <= bd) == 0ull) continue;
+      if (g.dbg && gq_lane() == 0) atomicAdd(&g.dbg[2], 1ull);
       const int fa = f0 + (sc - s0) * 16;
       const int fb = (fa + 16 < f1) ? fa + 16 : f1;
       GqFace cur = g.rec[fa];
@@ -272,13 +307,213 @@ __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
       best_g = gq_mv(Rl, gl);
     }
   }
-  if (!ok) return;
-  const size_t o = (size_t)row * g.P + pt;
-  g.dis[o] = (best_dis == -GQ_INF_F) ? -1e30f : best_dis;
-  g.link[o] = best_link;
-  g.gvec[o * 3 + 0] = best_g.x;
-  g.gvec[o * 3 + 1] = best_g.y;
-  g.gvec[o * 3 + 2] = best_g.z;
+  if (ok) {
+    const size_t o = (size_t)row * g.P + pt;
+    g.dis[o] = (best_dis == -GQ_INF_F) ? -1e30f : best_dis;
+    g.link[o] = best_link;
+    g.gvec[o * 3 + 0] = best_g.x;
+    g.gvec[o * 3 + 1] = best_g.y;
+    g.gvec[o * 3 + 2] = best_g.z;
+  }
+  if (g.span) {  // last store of the block is done: close the launch's time span
+    __syncthreads();
+    if (threadIdx.x == 0) gq_span_close(g.span);
+  }
+}
+
+// ---- load-balanced penetration-only query (penetration_only = 1 with a workspace) -------------------------------------
+// Only ~3 % of the (wavefront, link) combinations contain a point that can penetrate the link, but they cluster in a
+// few wavefronts (the points in the middle of the hand touch many links), so a single kernel ends on a handful of
+// waves that each walk 10+ link meshes.  The query is therefore split in three launches:
+//   scan      every wavefront tests its 64 points against every link (AABB + occupancy grid) and appends one work
+//             item (row, first point, link, 64-bit lane mask) per hit to a queue;
+//   eval      the queue is processed by 8192 wavefronts in parallel: one link mesh for <= 64 points per item; a
+//             penetrating point publishes max(dis) with a 64-bit atomicMax key (dis bits | 255-link | face), which is
+//             independent of the order in which items are processed;
+//   finalize  points with a key recompute closest point / gradient of the winning (link, face).
+struct GqPenItem {  // one surface point that may penetrate the queue's link
+  int row, pt;
+};
+struct GqPenQ {
+  GqPenItem* items;  // (L, cap_link): one queue per link so that a block can stage the link's mesh in LDS once
+  int* count;        // (L)
+  unsigned long long* keys;  // (B, P)
+  long long cap_link;        // = B * P: a queue can never overflow
+};
+
+__global__ __launch_bounds__(256) void gq_pen_scan_kernel(GqPenArgs g, GqPenQ q) {
+  extern __shared__ float s_link[];  // L x 24: link transform (12) + padded AABB (8) + occupancy z scale (1) + pad
+  const int row = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.span && threadIdx.x == 0) gq_span_open(g.span);
+  for (int i = threadIdx.x; i < g.L * 24; i += blockDim.x) {
+    const int l = i / 24, k = i % 24;
+    float v = 0.0f;
+    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
+    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
+    else if (k == 20) v = g.occ ? g.occ_invz[l] : 0.0f;
+    s_link[i] = v;
+  }
+  const bool ok = pt < g.P;
+  const int obj = row / g.batch_each;
+  const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
+  const float* hp = g.hand_pose + (size_t)row * g.D;
+  const float* R = g.Rg + (size_t)row * 9;
+  const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+  if (ok) q.keys[(size_t)row * g.P + pt] = 0ull;
+  __syncthreads();
+  const int lane = gq_lane();
+  for (int l = 0; l < g.L; ++l) {
+    const float* T = s_link + l * 24;
+    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
+    const float* bb = T + 12;
+    bool need = ok && (g.off[l + 1] > g.off[l]) && (gq_aabb_dist2(bb, xl) <= 0.0f);
+    if (need && g.occ) {
+      const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
+      const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
+      need = (g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u;
+    }
+    const unsigned long long m = __ballot(need);
+    if (m != 0ull) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&q.count[l], __popcll(m));
+      base = gq_readlane_i(base, 0);
+      if (need) {
+        GqPenItem it;
+        it.row = row;
+        it.pt = pt;
+        q.items[(size_t)l * q.cap_link + base + __popcll(m & ((1ull << lane) - 1ull))] = it;
+      }
+    }
+  }
+}
+
+// A block = 8 wavefronts takes one chunk of 64 queue entries of one link (chunks of all links are numbered
+// consecutively, so blocks spread over the queues in proportion to their length).  Lane j of EVERY wavefront owns
+// entry j; wavefront w ranks the w-th eighth of the link's faces (records are wave-uniform -> scalar loads), the eight
+// partial minima meet in LDS and wavefront 0 finishes the winner.  All 64 lanes work, a block lasts a few us, and
+// there are enough blocks (entries / 64) to cover the chip.
+#define GQ_PEN_EVAL_BLOCKS 4096
+__global__ __launch_bounds__(512) void gq_pen_eval_kernel(GqPenArgs g, GqPenQ q) {
+  __shared__ float s_d[8][GQ_WAVE];
+  __shared__ unsigned s_o[8][GQ_WAVE];
+  __shared__ int s_i[8][GQ_WAVE];
+  __shared__ int s_sel[2];
+  const int lane = gq_lane(), wv = threadIdx.x / GQ_WAVE;
+  for (int chunk = blockIdx.x;; chunk += gridDim.x) {
+    __syncthreads();  // LDS of the previous chunk fully consumed
+    if (threadIdx.x == 0) {
+      int c = chunk, l = 0;
+      for (; l < g.L; ++l) {
+        const int nc = (q.count[l] + GQ_WAVE - 1) / GQ_WAVE;
+        if (c < nc) break;
+        c -= nc;
+      }
+      s_sel[0] = (l < g.L) ? l : -1;
+      s_sel[1] = c;
+    }
+    __syncthreads();
+    const int l = s_sel[0];
+    if (l < 0) return;  // block-uniform: past the last chunk
+    const int count = q.count[l];
+    const int i = s_sel[1] * GQ_WAVE + lane;
+    const bool need = i < count;
+    const int f0 = g.off[l], f1 = g.off[l + 1];
+    GqPenItem it;
+    it.row = 0;
+    it.pt = 0;
+    if (need) it = q.items[(size_t)l * q.cap_link + i];
+    const int row = it.row, pt = it.pt;
+    const int obj = row / g.batch_each;
+    const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
+    const float* hp = g.hand_pose + (size_t)row * g.D;
+    const float* R = g.Rg + (size_t)row * 9;
+    const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
+    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
+    const int per = (f1 - f0 + 7) / 8;
+    const int fa = f0 + wv * per, fb = min(fa + per, f1);
+    float bd = GQ_INF_F;
+    unsigned bo = 0xffffffffu;
+    int bi = f0;
+    if (fa < fb) {
+      GqFace cur = g.rec[fa];
+      for (int f = fa; f < fb; ++f) {  // f is wave-uniform: scalar loads, next record prefetched
+        const GqFace nxt = g.rec[(f + 1 < fb) ? f + 1 : f];
+        const gq3 d = xl - gq_mk(cur.r0.x, cur.r0.y, cur.r0.z);
+        const float d2 = gq_tri_rank(cur, d);
+        const unsigned orig = (unsigned)__float_as_int(cur.r5.z);
+        if (d2 < bd || (d2 == bd && orig < bo)) {
+          bd = d2;
+          bo = orig;
+          bi = f;
+        }
+        cur = nxt;
+      }
+    }
+    s_d[wv][lane] = bd;
+    s_o[wv][lane] = bo;
+    s_i[wv][lane] = bi;
+    __syncthreads();
+    if (wv == 0 && need) {
+#pragma unroll
+      for (int w = 1; w < 8; ++w) {
+        const float d2 = s_d[w][lane];
+        const unsigned orig = s_o[w][lane];
+        if (d2 < bd || (d2 == bd && orig < bo)) {
+          bd = d2;
+          bo = orig;
+          bi = s_i[w][lane];
+        }
+      }
+      const GqSdfOut o = gq_tri_finish(g.rec[bi], xl);
+      if (o.sign < 0) {  // inside link l: dis = +sqrt(d^2 + 1e-8) > 0
+        const float dis = sqrtf(o.dist2 + 1e-8f);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dis) << 32) |
+                                       ((unsigned long long)(255 - l) << 24) | (unsigned long long)(bi - f0);
+        atomicMax(&q.keys[(size_t)row * g.P + pt], key);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gq_pen_finalize_kernel(GqPenArgs g, GqPenQ q) {
+  const int row = blockIdx.y;
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt < g.P) {
+    const size_t o = (size_t)row * g.P + pt;
+    const unsigned long long key = q.keys[o];
+    float dis = -1e30f;
+    int link = 0;
+    gq3 gh = gq_mk(0, 0, 0);
+    if (key != 0ull) {
+      link = 255 - (int)((key >> 24) & 0xffull);
+      const int face = g.off[link] + (int)(key & 0xffffffull);
+      const int obj = row / g.batch_each;
+      const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
+      const float* hp = g.hand_pose + (size_t)row * g.D;
+      const float* R = g.Rg + (size_t)row * 9;
+      const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+      const float* T = g.link_T + ((size_t)row * g.L + link) * 12;
+      const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+      const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
+      const GqSdfOut r = gq_tri_finish(g.rec[face], xl);
+      const float root = sqrtf(r.dist2 + 1e-8f);
+      dis = root * (float)(-r.sign);
+      gh = gq_mv(Rl, ((float)(-r.sign) / root) * (xl - r.closest));
+    }
+    g.dis[o] = dis;
+    g.link[o] = link;
+    g.gvec[o * 3 + 0] = gh.x;
+    g.gvec[o * 3 + 1] = gh.y;
+    g.gvec[o * 3 + 2] = gh.z;
+  }
+  if (g.span) {
+    __syncthreads();
+    if (threadIdx.x == 0) gq_span_close(g.span);
+  }
 }
 
 // Backward of the hand-penetration query for an upstream gradient w (B,P) on `dis`:
@@ -365,6 +600,59 @@ __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
   }
 }
 
+// ---- occupancy grid construction (setup) ---------------------------------------------------------------------------
+__global__ void gq_occ_faces_kernel(const GqFace* __restrict__ rec, const int32_t* __restrict__ off, int n_mesh,
+                                    const float* __restrict__ aabb, const float* __restrict__ invz,
+                                    uint32_t* __restrict__ occ) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= off[n_mesh]) return;
+  int m = 0;
+  while (m + 1 < n_mesh && f >= off[m + 1]) ++m;
+  const GqFace fc = rec[f];
+  const gq3 a = gq_mk(fc.r0.x, fc.r0.y, fc.r0.z);
+  const gq3 b = a + gq_mk(fc.r1.x, fc.r1.y, fc.r1.z), c = a + gq_mk(fc.r2.x, fc.r2.y, fc.r2.z);
+  const float* bb = aabb + m * 8;
+  const float sc[3] = {bb[3], bb[7], invz[m]};
+  const float lo[3] = {fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z)};
+  const float hi[3] = {fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z)};
+  int i0[3], i1[3];
+  for (int k = 0; k < 3; ++k) {  // one extra voxel of margin on both sides
+    i0[k] = min(max((int)floorf((lo[k] - bb[k]) * sc[k]) - 1, 0), 31);
+    i1[k] = min(max((int)floorf((hi[k] - bb[k]) * sc[k]) + 1, 0), 31);
+  }
+  const uint32_t xm = (i1[0] >= 31 ? 0xffffffffu : ((1u << (i1[0] + 1)) - 1u)) & ~((1u << i0[0]) - 1u);
+  for (int iz = i0[2]; iz <= i1[2]; ++iz)
+    for (int iy = i0[1]; iy <= i1[1]; ++iy) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], xm);
+}
+
+// one thread per voxel centre of mesh blockIdx.y: brute-force closest face -> inside?  (32768 centres per mesh)
+__global__ __launch_bounds__(256) void gq_occ_centres_kernel(const GqFace* __restrict__ rec,
+                                                             const int32_t* __restrict__ off,
+                                                             const float* __restrict__ aabb,
+                                                             const float* __restrict__ invz, uint32_t* __restrict__ occ) {
+  const int m = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;  // 0..32767
+  const int ix = v & 31, iy = (v >> 5) & 31, iz = v >> 10;
+  const float* bb = aabb + m * 8;
+  const gq3 p = gq_mk(bb[0] + ((float)ix + 0.5f) / bb[3], bb[1] + ((float)iy + 0.5f) / bb[7],
+                      bb[2] + ((float)iz + 0.5f) / invz[m]);
+  const int f0 = off[m], f1 = off[m + 1];
+  float best = GQ_INF_F;
+  int bi = -1;
+  for (int f = f0; f < f1; ++f) {
+    const GqFace fc = rec[f];
+    const float d2 = gq_tri_rank(fc, p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
+    if (d2 < best) {
+      best = d2;
+      bi = f;
+    }
+  }
+  if (bi >= 0) {
+    const GqSdfOut o = gq_tri_finish(rec[bi], p);
+    if (o.sign < 0) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], 1u << ix);
+  }
+}
+
 // ---- mesh-set handle: concatenated face records of n_mesh meshes on the device -----------------------------------
 struct gqMeshSet {
   GqFace* rec;         // records, faces Morton-sorted inside each mesh
@@ -375,6 +663,8 @@ struct gqMeshSet {
   int32_t* sub_off_dev;   // (n_mesh+1)
   float* cl_aabb_dev;  // (n_cl, 8) boxes of 64-face clusters
   int32_t* cl_off_dev;    // (n_mesh+1)
+  uint32_t* occ_dev;   // (n_mesh, 1024) occupancy bits or null (gq_meshset_build_occupancy)
+  float* occ_invz_dev; // (n_mesh)
   int n_mesh;
   int64_t n_faces;
 };
@@ -405,7 +695,15 @@ static void gq_box_of(const float* fv, const int32_t* perm, int64_t a, int64_t b
   out8[4] = hi[0]; out8[5] = hi[1]; out8[6] = hi[2]; out8[7] = 0.0f;
 }
 
+static unsigned long long* gq_pen_dbg_ = nullptr;
+
 extern "C" {
+
+// diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
+int gq_debug_set_pen_counters(uint64_t* counters) {
+  gq_pen_dbg_ = (unsigned long long*)counters;
+  return GQ_OK;
+}
 
 int gq_meshset_create(const float* face_verts_host, const int32_t* face_offset_host, int n_mesh, gqMeshSet** out) {
   GQ_REQUIRE(face_verts_host && face_offset_host && out && n_mesh > 0, "meshset_create: bad arguments");
@@ -482,6 +780,42 @@ int gq_meshset_create(const float* face_verts_host, const int32_t* face_offset_h
   return GQ_OK;
 }
 
+// Occupancy grid of every mesh (setup-time).  Voxel (ix,iy,iz) of the 32^3 grid over the mesh AABB is marked when
+// (a) the bounding box of some face overlaps it, or (b) its centre is inside the mesh (sign of the closest face).
+// An unmarked voxel does not touch the surface, so it lies entirely on one side, and (b) says it is outside.
+int gq_meshset_build_occupancy(gqMeshSet* ms) {
+  GQ_REQUIRE(ms, "meshset_build_occupancy: null");
+  if (ms->occ_dev) return GQ_OK;
+  const int n = ms->n_mesh;
+  std::vector<float> bb((size_t)n * 8), invz(n);
+  GQ_CHECK_HIP(hipMemcpy(bb.data(), ms->aabb_dev, sizeof(float) * n * 8, hipMemcpyDeviceToHost));
+  for (int m = 0; m < n; ++m) {
+    // grow the box a little so that surface points are strictly inside the grid, then store 32/extent
+    for (int c = 0; c < 3; ++c) {
+      const float ext = bb[m * 8 + 4 + c] - bb[m * 8 + c];
+      const float pad = 1e-4f * ext + 1e-7f;
+      bb[m * 8 + c] -= pad;
+      bb[m * 8 + 4 + c] += pad;
+    }
+    bb[m * 8 + 3] = 32.0f / (bb[m * 8 + 4] - bb[m * 8 + 0]);
+    bb[m * 8 + 7] = 32.0f / (bb[m * 8 + 5] - bb[m * 8 + 1]);
+    invz[m] = 32.0f / (bb[m * 8 + 6] - bb[m * 8 + 2]);
+  }
+  GQ_CHECK_HIP(hipMemcpy(ms->aabb_dev, bb.data(), sizeof(float) * n * 8, hipMemcpyHostToDevice));
+  GQ_CHECK_HIP(hipMalloc(&ms->occ_invz_dev, sizeof(float) * n));
+  GQ_CHECK_HIP(hipMemcpy(ms->occ_invz_dev, invz.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  GQ_CHECK_HIP(hipMalloc(&ms->occ_dev, sizeof(uint32_t) * n * 1024));
+  GQ_CHECK_HIP(hipMemset(ms->occ_dev, 0, sizeof(uint32_t) * n * 1024));
+  hipLaunchKernelGGL(gq_occ_faces_kernel, dim3((unsigned)((ms->n_faces + 255) / 256)), dim3(256), 0, 0, ms->rec,
+                     ms->off_dev, n, ms->aabb_dev, ms->occ_invz_dev, ms->occ_dev);
+  GQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gq_occ_centres_kernel, dim3(128, (unsigned)n), dim3(256), 0, 0, ms->rec, ms->off_dev, ms->aabb_dev,
+                     ms->occ_invz_dev, ms->occ_dev);
+  GQ_LAUNCH_CHECK();
+  GQ_CHECK_HIP(hipDeviceSynchronize());
+  return GQ_OK;
+}
+
 int gq_meshset_destroy(gqMeshSet* ms) {
   if (!ms) return GQ_OK;
   (void)hipFree(ms->rec);
@@ -491,6 +825,8 @@ int gq_meshset_destroy(gqMeshSet* ms) {
   (void)hipFree(ms->cl_aabb_dev);
   (void)hipFree(ms->sub_off_dev);
   (void)hipFree(ms->cl_off_dev);
+  if (ms->occ_dev) (void)hipFree(ms->occ_dev);
+  if (ms->occ_invz_dev) (void)hipFree(ms->occ_invz_dev);
   delete[] ms->off_host;
   delete ms;
   return GQ_OK;
@@ -581,7 +917,8 @@ int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float*
 // Fused hand-penetration query (HandModel.cal_distance, hand_model.py:875-987).
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                         int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
-                        int penetration_only, float* dis, int32_t* link, float* gvec, void* timer, void* stream) {
+                        int penetration_only, float* dis, int32_t* link, float* gvec, void* workspace,
+                        size_t workspace_bytes, void* timer, uint64_t* span, void* stream) {
   GQ_REQUIRE(links && surface_points && hand_pose && Rg && link_T && dis && link && gvec, "hand_pen_forward: null");
   GQ_REQUIRE(n_obj > 0 && n_surface > 0 && batch_each > 0 && pose_dim >= 9, "hand_pen_forward: bad sizes");
   GqPenArgs a{};
@@ -594,6 +931,8 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   a.aabb = links->aabb_dev;
   a.sub_aabb = links->sub_aabb_dev;
   a.sub_off = links->sub_off_dev;
+  a.occ = links->occ_dev;
+  a.occ_invz = links->occ_invz_dev;
   a.B = (int)(n_obj * batch_each);
   a.P = (int)n_surface;
   a.L = links->n_mesh;
@@ -602,6 +941,8 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   a.dis = dis;
   a.link = link;
   a.gvec = gvec;
+  a.span = span;
+  a.dbg = gq_pen_dbg_;
   GQ_REQUIRE(a.B <= 65535, "hand_pen_forward: B=%d exceeds grid.y limit", a.B);
   const dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)a.B);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -609,11 +950,39 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     e0 = ((hipEvent_t*)timer)[0];
     e1 = ((hipEvent_t*)timer)[1];
   }
-  if (penetration_only)
+  if (penetration_only == 1 && workspace != nullptr) {
+    // queue-based, load-balanced path (see gq_pen_scan_kernel)
+    const size_t cap_link = (size_t)a.B * a.P;
+    const size_t cap = cap_link * a.L;
+    const size_t need = 1024 + cap * sizeof(GqPenItem) + (size_t)a.B * a.P * 8;
+    GQ_REQUIRE(workspace_bytes >= need, "hand_pen_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+    GQ_REQUIRE(a.L <= 255 && cap_link < (1ull << 31), "hand_pen_forward: too many links / items for the queue path");
+    GqPenQ q;
+    q.count = (int*)workspace;
+    q.items = (GqPenItem*)((char*)workspace + 1024);
+    q.keys = (unsigned long long*)((char*)workspace + 1024 + cap * sizeof(GqPenItem));
+    q.cap_link = (long long)cap_link;
+    GQ_CHECK_HIP(hipMemsetAsync(q.count, 0, sizeof(int) * a.L, (hipStream_t)stream));
+    hipExtLaunchKernelGGL(gq_pen_scan_kernel, grid, dim3(256), (size_t)a.L * 24 * sizeof(float), (hipStream_t)stream, e0,
+                          nullptr, 0, a, q);
+    GQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gq_pen_eval_kernel, dim3(GQ_PEN_EVAL_BLOCKS), dim3(512), 0, (hipStream_t)stream, a, q);
+    GQ_LAUNCH_CHECK();
+    hipExtLaunchKernelGGL(gq_pen_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0, a, q);
+  } else if (penetration_only == 1)
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  else if (penetration_only == 2)  // AABB test only, no occupancy grid (kept for A/B tests)
+    hipExtLaunchKernelGGL(gq_hand_pen_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   else
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes) {
+  GQ_REQUIRE(bytes && batch > 0 && n_surface > 0 && n_links > 0, "hand_pen_workspace_bytes: bad arguments");
+  const size_t cap = (size_t)batch * n_surface * n_links;
+  *bytes = 1024 + cap * sizeof(GqPenItem) + (size_t)batch * n_surface * 8;
   return GQ_OK;
 }
 

@@ -326,6 +326,7 @@ class HandHandle:
         _C.call("gq_hand_create", ctypes.byref(d), ctypes.byref(h))
         self.handle = h
         self.links = MeshSet([spec.link_faces(l) for l in range(spec.n_links)])
+        _C.call("gq_meshset_build_occupancy", self.links.handle)
         self.J, self.L, self.S = spec.n_dofs, spec.n_links, spec.n_spheres
 
     def fk_ws(self, B, dev):
@@ -408,9 +409,13 @@ class _HandPen(torch.autograd.Function):
         dis = torch.empty(B, P, device=dev)
         link = torch.empty(B, P, dtype=torch.int32, device=dev)
         gvec = torch.empty(B, P, 3, device=dev)
+        pws, pnb = None, 0
+        if int(penetration_only) == 1:
+            pnb = _size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), hand.L)
+            pws = _ws(pnb, dev)
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
-                _C.f32(Rg), _C.f32(LT), int(bool(penetration_only)), _C.f32(dis), _C.i32(link), _C.f32(gvec), None,
-                _C.stream_ptr())
+                _C.f32(Rg), _C.f32(LT), int(penetration_only), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.ptr(pws), pnb,
+                None, None, _C.stream_ptr())
         ctx.save_for_backward(hp, sp, idx, Rg, LT, ws, link, gvec)
         ctx.hand, ctx.batch_each, ctx.nb = hand, int(batch_each), nb
         return dis

@@ -83,9 +83,12 @@ class GraspStepper:
         self.fc_nb = ops._size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, int(self.fc["n_cone_vecs"]),
                                     int(self.fc["max_iter"]))
         self.fc_ws = ops._ws(self.fc_nb, self.dev)
+        self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
+        self.pen_ws = ops._ws(self.pen_nb, self.dev)
         self._graph = None
         self.kernel_events = None
-        self.penetration_only = bool(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
+        self._span = None
+        self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
     def _eval_pre(self, pose, idx, st):
@@ -103,12 +106,14 @@ class GraspStepper:
           float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
           _C.ptr(self.fc_ws), self.fc_nb, st)
 
-    def _eval_pen(self, pose, st, timer=None):
-        """The dominant kernel, kept as a launch of its own so bench.py can time it (gqTimer = HIP events filled with
-        the kernel's own start/stop timestamps by hipExtLaunchKernelGGL)."""
+    def _eval_pen(self, pose, st, timer=None, span=None):
+        """The dominant kernel, kept as a launch of its own so bench.py can time it live: ``timer`` = HIP event pair
+        (hipExtLaunchKernelGGL start/stop events), ``span`` = device pointer to {min block start, max block end} in
+        100 MHz s_memrealtime ticks (the kernel's own execution span, what rocprofv3 reports)."""
         _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
                 _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
-                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec), timer, st)
+                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
+                _C.ptr(self.pen_ws) if self.penetration_only == 1 else None, self.pen_nb, timer, span, st)
 
     def _eval_post(self, pose, idx, st):
         B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
@@ -189,21 +194,38 @@ class GraspStepper:
         if ev is None:
             self._eval_pen(self.pose_new, st)
             return
+        i = len(ev)
+        if i >= self._span.shape[0]:
+            self._eval_pen(self.pose_new, st)
+            return
         t = ctypes.c_void_p(0)
         _C.call("gq_timer_create", ctypes.byref(t))
-        self._eval_pen(self.pose_new, st, t)
+        self._eval_pen(self.pose_new, st, t, ctypes.c_void_p(self._span[i].data_ptr()))
         ev.append(t)
 
+    def start_kernel_timing(self, max_launches=4096):
+        """Time every hand-penetration launch from now on (bench.py)."""
+        self._span = torch.zeros(max_launches, 64, 2, dtype=torch.int64, device=self.dev)
+        self._span[:, :, 0] = -1  # 0xffff... as unsigned: atomicMin target (64 shards per launch)
+        self.kernel_events = []
+
     def kernel_times_ms(self):
-        """Durations (ms) of the timed hand-penetration launches collected since ``kernel_events = []``."""
-        out = []
+        """-> (event_ms, span_ms): per-launch durations from the HIP event pairs and from the in-kernel
+        s_memrealtime span (100 MHz) of the launches timed since ``start_kernel_timing``."""
+        ev_ms = []
         for t in self.kernel_events or []:
             ms = ctypes.c_float(0)
             _C.call("gq_timer_elapsed_ms", t, ctypes.byref(ms))
             _C.call("gq_timer_destroy", t)
-            out.append(float(ms.value))
+            ev_ms.append(float(ms.value))
+        n = len(ev_ms)
+        sp = self._span[:n].cpu()
+        used = sp[:, :, 1] > 0  # shards that saw a block
+        start = torch.where(used, sp[:, :, 0], torch.full_like(sp[:, :, 0], 2**62)).min(dim=1).values
+        end = sp[:, :, 1].max(dim=1).values
+        span_ms = ((end - start).double() / 1e5).tolist()  # ticks of 10 ns -> ms
         self.kernel_events = None
-        return out
+        return ev_ms, span_ms
 
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""

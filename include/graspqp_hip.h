@@ -38,6 +38,8 @@ typedef struct gqMeshSet gqMeshSet; /* n_mesh triangle soups resident on the dev
 int gq_meshset_create(const float* face_verts_host /* (sumF,3,3) */, const int32_t* face_offset_host /* (n_mesh+1) */,
                       int n_mesh, gqMeshSet** out);
 int gq_meshset_destroy(gqMeshSet* ms);
+/* setup-time 32^3 occupancy grid per mesh; enables the penetration_only = 1 fast path of gq_hand_pen_forward */
+int gq_meshset_build_occupancy(gqMeshSet* ms);
 int gq_meshset_num_faces(const gqMeshSet* ms, int mesh /* -1 = all */, int64_t* n);
 int gq_sdf_workspace_bytes(int64_t n_faces, size_t* bytes);
 int gq_sdf_forward(const float* points /* (N,3) */, int64_t n_points, const float* face_verts /* (F,3,3) */,
@@ -129,7 +131,12 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
                         int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                         const float* link_T, int penetration_only, float* dis, int32_t* link, float* gvec,
-                        void* timer /* gqTimer or NULL */, void* stream);
+                        void* workspace /* NULL, or gq_hand_pen_workspace_bytes: enables the load-balanced path */,
+                        size_t workspace_bytes, void* timer /* gqTimer or NULL */,
+                        uint64_t* span /* NULL, or {min start, max end} in 100 MHz device ticks, pre-set to {~0, 0} */,
+                        void* stream);
+int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes);
+int gq_debug_set_pen_counters(uint64_t* counters /* device, 4 words, or NULL */);
 int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                          const float* grad_dis /* (B,P) */, const int32_t* link, const float* gvec,

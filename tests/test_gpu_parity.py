@@ -277,10 +277,19 @@ def test_hand_penetration_and_self_penetration(gq):
     assert torch.equal(dis2, dis)
     # penetration-only mode (what E_pen uses): same values where dis > 0 (two template instantiations of one
     # kernel: FMA contraction may differ in the last bit), non-positive elsewhere
-    dis3 = hm.cal_distance(om.surface_points_each, penetration_only=True)
     pos = dis > 1e-6
-    torch.testing.assert_close(dis3[pos], dis[pos], rtol=1e-5, atol=1e-8)
-    assert (dis3[dis <= -1e-6] <= 0).all()
+    for mode in (1, 2):  # 1 = occupancy-grid culling, 2 = AABB culling only
+        dis3 = hm.cal_distance(om.surface_points_each, penetration_only=mode)
+        # ranking distances carry ~1e-10 m^2 of round-off -> near-tied faces may swap: 3e-6 m on the distance
+        torch.testing.assert_close(dis3[pos], dis[pos], rtol=2e-4, atol=3e-6)
+        assert (dis3[dis <= -1e-6] <= 0).all()
+    # gradients through the compacted kernel == through the exact kernel
+    grads = []
+    for mode in (1, 0):
+        hm.set_parameters(hp.float().cuda().requires_grad_(), idx.cuda())
+        torch.relu(hm.cal_distance(om.surface_points_each, penetration_only=mode)).sum().backward()
+        grads.append(hm.hand_pose.grad.clone())
+    assert (grads[0] - grads[1]).norm() <= 5e-3 * grads[1].norm()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -8,8 +8,9 @@
 #include "common.h"
 
 struct gqHand {
-  int J, L, C, S, NG;
+  int J, L, C, S, NG, max_depth;
   int32_t *node_parent, *node_type, *link_node, *cand_link, *sphere_link, *group_off;
+  int32_t *node_depth, *child_off, *child_idx;  // tree levels and per-node child lists (wave-parallel FK)
   float *node_pre, *node_axis, *link_offset, *cand_pos, *cand_nrm, *sphere, *jlo, *jhi;
 };
 
@@ -102,36 +103,47 @@ struct GqFkArgs {
   float* spheres;   // (B, S, 3) or null
 };
 
-__global__ __launch_bounds__(64) void gq_fk_forward_kernel(GqFkArgs g) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.B) return;
+// one wavefront per row: lane j owns joint node j, then link j, then contacts / spheres j, j+64, ...
+__global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
+  __shared__ float sW[64 * 12];
+  __shared__ float sT[64 * 12];
+  const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   float R[9];
   gq_rot6d(hp + 3, R);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) g.Rg[(size_t)row * 9 + i] = R[i];
+  if (lane < 9) g.Rg[(size_t)row * 9 + lane] = R[lane];
   const gq3 tg = gq_mk(hp[0], hp[1], hp[2]);
-  float* W = g.node_W + (size_t)row * h.J * 12;
-  for (int j = 0; j < h.J; ++j) {
-    const int p = h.node_parent[j];
-    const GqT pre = gq_t_load(h.node_pre + j * 12);
-    const gq3 ax = gq_mk(h.node_axis[j * 3], h.node_axis[j * 3 + 1], h.node_axis[j * 3 + 2]);
-    GqT A = gq_t_mul(pre, gq_joint_motion(h.node_type[j], ax, hp[9 + j]));
-    if (p >= 0) A = gq_t_mul(gq_t_load(W + p * 12), A);
-    gq_t_store(W + j * 12, A);
+  GqT A = gq_t_identity();
+  int parent = -1, depth = -1;
+  if (lane < h.J) {
+    parent = h.node_parent[lane];
+    depth = h.node_depth[lane];
+    const GqT pre = gq_t_load(h.node_pre + lane * 12);
+    const gq3 ax = gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]);
+    A = gq_t_mul(pre, gq_joint_motion(h.node_type[lane], ax, hp[9 + lane]));
+    if (parent < 0) gq_t_store(sW + lane * 12, A);
   }
-  float* LT = g.link_T + (size_t)row * h.L * 12;
-  for (int l = 0; l < h.L; ++l) {
-    const int nd = h.link_node[l];
-    GqT T = gq_t_load(h.link_offset + l * 12);
-    if (nd >= 0) T = gq_t_mul(gq_t_load(W + nd * 12), T);
-    gq_t_store(LT + l * 12, T);
+  __syncthreads();
+  for (int d = 1; d <= h.max_depth; ++d) {  // level by level down the tree
+    if (depth == d) {
+      A = gq_t_mul(gq_t_load(sW + parent * 12), A);
+      gq_t_store(sW + lane * 12, A);
+    }
+    __syncthreads();
   }
-  for (int c = 0; c < g.n; ++c) {
+  if (lane < h.J) gq_t_store(g.node_W + ((size_t)row * h.J + lane) * 12, A);
+  if (lane < h.L) {
+    const int nd = h.link_node[lane];
+    GqT T = gq_t_load(h.link_offset + lane * 12);
+    if (nd >= 0) T = gq_t_mul(gq_t_load(sW + nd * 12), T);
+    gq_t_store(sT + lane * 12, T);
+    gq_t_store(g.link_T + ((size_t)row * h.L + lane) * 12, T);
+  }
+  __syncthreads();
+  for (int c = lane; c < g.n; c += GQ_WAVE) {
     const int ci = (int)g.idx[(size_t)row * g.n + c];
-    const int l = h.cand_link[ci];
-    const GqT T = gq_t_load(LT + l * 12);
+    const GqT T = gq_t_load(sT + h.cand_link[ci] * 12);
     const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
     const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
     const gq3 pw = gq_mv(R, ph) + tg;
@@ -142,11 +154,11 @@ __global__ __launch_bounds__(64) void gq_fk_forward_kernel(GqFkArgs g) {
     o[0] = nw.x; o[1] = nw.y; o[2] = nw.z;
   }
   if (g.spheres) {
-    for (int s = 0; s < h.S; ++s) {
-      const GqT T = gq_t_load(LT + h.sphere_link[s] * 12);
-      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[s * 4], h.sphere[s * 4 + 1], h.sphere[s * 4 + 2]));
+    for (int sidx = lane; sidx < h.S; sidx += GQ_WAVE) {
+      const GqT T = gq_t_load(sT + h.sphere_link[sidx] * 12);
+      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[sidx * 4], h.sphere[sidx * 4 + 1], h.sphere[sidx * 4 + 2]));
       const gq3 pw = gq_mv(R, ph) + tg;
-      float* o = g.spheres + ((size_t)row * h.S + s) * 3;
+      float* o = g.spheres + ((size_t)row * h.S + sidx) * 3;
       o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
     }
   }
@@ -176,118 +188,158 @@ __device__ __forceinline__ void gq_add6(float* a, gq3 f, gq3 m) {
   a[3] += m.x; a[4] += m.y; a[5] += m.z;
 }
 
-__global__ __launch_bounds__(64) void gq_fk_backward_kernel(GqFkBwdArgs g) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= g.B) return;
+// one wavefront per row.  Items (contacts, spheres) are processed one per lane into (f, m, node) records in LDS; lane j
+// then folds, in item order, the records and link wrenches that ride on node j; children are folded into parents level
+// by level; the twelve global-pose sums use the fixed DPP tree.  Every sum has a fixed order -> reproducible.
+#define GQ_FK_MAX_ITEMS 320
+__global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) {
+  __shared__ float sI[GQ_FK_MAX_ITEMS * 6];
+  __shared__ int sIn[GQ_FK_MAX_ITEMS];
+  __shared__ float sNF[64 * 6];
+  const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
   const float* LT = g.link_T + (size_t)row * h.L * 12;
   const float* W = g.node_W + (size_t)row * h.J * 12;
-  float* NF = g.node_F + (size_t)row * h.J * 6;
-  for (int i = 0; i < h.J * 6; ++i) NF[i] = 0.0f;
-  gq3 gt = gq_mk(0, 0, 0);
-  float gR[9];
+  const int n_c = (g.g_cpts || g.g_cnrm) ? g.n : 0;
+  const int n_s = g.g_spheres ? h.S : 0;
+  const int n_items = n_c + n_s;
+  // ---- items: per-lane contribution to the global pose + (f, m) on the carrying node -----------------------------
+  float acc[12];  // gt (3), gR (9) partial sums of this lane
 #pragma unroll
-  for (int i = 0; i < 9; ++i) gR[i] = g.g_R ? g.g_R[(size_t)row * 9 + i] : 0.0f;
-
-  if (g.g_Rt) {  // grad_t = -R gsum ; grad_R = R K
-    const float* e = g.g_Rt + (size_t)row * 12;
-    gt = gt - gq_mv(R, gq_mk(e[0], e[1], e[2]));
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        gR[i * 3 + j] += R[i * 3 + 0] * e[3 + 0 * 3 + j] + R[i * 3 + 1] * e[3 + 1 * 3 + j] + R[i * 3 + 2] * e[3 + 2 * 3 + j];
-  }
-  if (g.g_wrench) {
-    for (int l = 0; l < h.L; ++l) {
-      const int nd = h.link_node[l];
-      if (nd < 0) continue;
-      const float* w = g.g_wrench + ((size_t)row * h.L + l) * 6;
-      gq_add6(NF + nd * 6, gq_mk(w[0], w[1], w[2]), gq_mk(w[3], w[4], w[5]));
-    }
-  }
-  if (g.g_cpts || g.g_cnrm) {
-    for (int c = 0; c < g.n; ++c) {
-      const int ci = (int)g.idx[(size_t)row * g.n + c];
-      const int l = h.cand_link[ci];
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  for (int it = lane; it < n_items; it += GQ_WAVE) {
+    gq3 f = gq_mk(0, 0, 0), m = gq_mk(0, 0, 0);
+    int l;
+    if (it < n_c) {
+      const int ci = (int)g.idx[(size_t)row * g.n + it];
+      l = h.cand_link[ci];
       const GqT T = gq_t_load(LT + l * 12);
       const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
       const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
-      gq3 f = gq_mk(0, 0, 0), m = gq_mk(0, 0, 0);
       if (g.g_cpts) {
-        const float* q = g.g_cpts + ((size_t)row * g.n + c) * 3;
+        const float* q = g.g_cpts + ((size_t)row * g.n + it) * 3;
         const gq3 gp = gq_mk(q[0], q[1], q[2]);
-        gt = gt + gp;
-        gR[0] += gp.x * ph.x; gR[1] += gp.x * ph.y; gR[2] += gp.x * ph.z;
-        gR[3] += gp.y * ph.x; gR[4] += gp.y * ph.y; gR[5] += gp.y * ph.z;
-        gR[6] += gp.z * ph.x; gR[7] += gp.z * ph.y; gR[8] += gp.z * ph.z;
+        acc[0] += gp.x; acc[1] += gp.y; acc[2] += gp.z;
+        acc[3] += gp.x * ph.x; acc[4] += gp.x * ph.y; acc[5] += gp.x * ph.z;
+        acc[6] += gp.y * ph.x; acc[7] += gp.y * ph.y; acc[8] += gp.y * ph.z;
+        acc[9] += gp.z * ph.x; acc[10] += gp.z * ph.y; acc[11] += gp.z * ph.z;
         const gq3 gph = gq_mtv(R, gp);
         f = f + gph;
         m = m + gq_cross(ph, gph);
       }
       if (g.g_cnrm) {
-        const float* q = g.g_cnrm + ((size_t)row * g.n + c) * 3;
+        const float* q = g.g_cnrm + ((size_t)row * g.n + it) * 3;
         const gq3 gn = gq_mk(q[0], q[1], q[2]);
-        gR[0] += gn.x * nh.x; gR[1] += gn.x * nh.y; gR[2] += gn.x * nh.z;
-        gR[3] += gn.y * nh.x; gR[4] += gn.y * nh.y; gR[5] += gn.y * nh.z;
-        gR[6] += gn.z * nh.x; gR[7] += gn.z * nh.y; gR[8] += gn.z * nh.z;
+        acc[3] += gn.x * nh.x; acc[4] += gn.x * nh.y; acc[5] += gn.x * nh.z;
+        acc[6] += gn.y * nh.x; acc[7] += gn.y * nh.y; acc[8] += gn.y * nh.z;
+        acc[9] += gn.z * nh.x; acc[10] += gn.z * nh.y; acc[11] += gn.z * nh.z;
         m = m + gq_cross(nh, gq_mtv(R, gn));
       }
-      const int nd = h.link_node[l];
-      if (nd >= 0) gq_add6(NF + nd * 6, f, m);
+    } else {
+      const int sidx = it - n_c;
+      l = h.sphere_link[sidx];
+      const float* q = g.g_spheres + ((size_t)row * h.S + sidx) * 3;
+      const gq3 gp = gq_mk(q[0], q[1], q[2]);
+      const GqT T = gq_t_load(LT + l * 12);
+      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[sidx * 4], h.sphere[sidx * 4 + 1], h.sphere[sidx * 4 + 2]));
+      acc[0] += gp.x; acc[1] += gp.y; acc[2] += gp.z;
+      acc[3] += gp.x * ph.x; acc[4] += gp.x * ph.y; acc[5] += gp.x * ph.z;
+      acc[6] += gp.y * ph.x; acc[7] += gp.y * ph.y; acc[8] += gp.y * ph.z;
+      acc[9] += gp.z * ph.x; acc[10] += gp.z * ph.y; acc[11] += gp.z * ph.z;
+      const gq3 gph = gq_mtv(R, gp);
+      f = gph;
+      m = gq_cross(ph, gph);
+    }
+    if (it < GQ_FK_MAX_ITEMS) {
+      sI[it * 6 + 0] = f.x; sI[it * 6 + 1] = f.y; sI[it * 6 + 2] = f.z;
+      sI[it * 6 + 3] = m.x; sI[it * 6 + 4] = m.y; sI[it * 6 + 5] = m.z;
+      sIn[it] = h.link_node[l];
     }
   }
-  if (g.g_spheres) {
-    for (int s = 0; s < h.S; ++s) {
-      const float* q = g.g_spheres + ((size_t)row * h.S + s) * 3;
-      const gq3 gp = gq_mk(q[0], q[1], q[2]);
-      if (gp.x == 0.0f && gp.y == 0.0f && gp.z == 0.0f) continue;
-      const int l = h.sphere_link[s];
-      const GqT T = gq_t_load(LT + l * 12);
-      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[s * 4], h.sphere[s * 4 + 1], h.sphere[s * 4 + 2]));
-      gt = gt + gp;
-      gR[0] += gp.x * ph.x; gR[1] += gp.x * ph.y; gR[2] += gp.x * ph.z;
-      gR[3] += gp.y * ph.x; gR[4] += gp.y * ph.y; gR[5] += gp.y * ph.z;
-      gR[6] += gp.z * ph.x; gR[7] += gp.z * ph.y; gR[8] += gp.z * ph.z;
-      const gq3 gph = gq_mtv(R, gp);
-      const int nd = h.link_node[l];
-      if (nd >= 0) gq_add6(NF + nd * 6, gph, gq_cross(ph, gph));
+  __syncthreads();
+  // ---- node accumulators: link wrenches (E_pen) then items, each in index order ---------------------------------------
+  float nf[6] = {0, 0, 0, 0, 0, 0};
+  if (lane < h.J) {
+    if (g.g_wrench) {
+      for (int l = 0; l < h.L; ++l) {
+        if (h.link_node[l] != lane) continue;
+        const float* w = g.g_wrench + ((size_t)row * h.L + l) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nf[k] += w[k];
+      }
     }
+    for (int it = 0; it < n_items; ++it) {
+      if (sIn[it] != lane) continue;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) nf[k] += sI[it * 6 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sNF[lane * 6 + k] = nf[k];
+  }
+  __syncthreads();
+  // ---- fold children into parents, deepest level first ----------------------------------------------------------------
+  const int depth = (lane < h.J) ? h.node_depth[lane] : -1;
+  for (int d = h.max_depth - 1; d >= 0; --d) {
+    if (depth == d) {
+      for (int k = h.child_off[lane]; k < h.child_off[lane + 1]; ++k) {
+        const int c = h.child_idx[k];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nf[q] += sNF[c * 6 + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) sNF[lane * 6 + q] = nf[q];
+    }
+    __syncthreads();
   }
   float* go = g.grad_pose + (size_t)row * g.D;
-  // joints, leaves to root: d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
-  for (int j = h.J - 1; j >= 0; --j) {
-    const float* w = NF + j * 6;
-    const gq3 f = gq_mk(w[0], w[1], w[2]), m = gq_mk(w[3], w[4], w[5]);
-    const GqT Wj = gq_t_load(W + j * 12);
-    const gq3 aw = gq_t_rot(Wj, gq_mk(h.node_axis[j * 3], h.node_axis[j * 3 + 1], h.node_axis[j * 3 + 2]));
+  if (lane < h.J) {  // d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
+    const gq3 f = gq_mk(nf[0], nf[1], nf[2]), m = gq_mk(nf[3], nf[4], nf[5]);
+    const GqT Wj = gq_t_load(W + lane * 12);
+    const gq3 aw = gq_t_rot(Wj, gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]));
     const gq3 o = gq_t_pos(Wj);
-    float gth = (h.node_type[j] == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
-    if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + j];
-    go[9 + j] = gth;
-    const int p = h.node_parent[j];
-    if (p >= 0) gq_add6(NF + p * 6, f, m);
+    float gth = (h.node_type[lane] == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
+    if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + lane];
+    go[9 + lane] = gth;
   }
-  go[0] = gt.x; go[1] = gt.y; go[2] = gt.z;
-  // Gram-Schmidt backward: columns of gR are the gradients of x, y, z
-  const gq3 a = gq_mk(hp[3], hp[4], hp[5]), b = gq_mk(hp[6], hp[7], hp[8]);
-  const float na = sqrtf(gq_dot(a, a));
-  const gq3 x = (1.0f / na) * a;
-  const gq3 yp = b - gq_dot(x, b) * x;
-  const float ny = sqrtf(gq_dot(yp, yp));
-  const gq3 y = (1.0f / ny) * yp;
-  gq3 gx = gq_mk(gR[0], gR[3], gR[6]), gy = gq_mk(gR[1], gR[4], gR[7]);
-  const gq3 gz = gq_mk(gR[2], gR[5], gR[8]);
-  gx = gx + gq_cross(y, gz);
-  gy = gy + gq_cross(gz, x);
-  const gq3 gyp = (1.0f / ny) * (gy - gq_dot(gy, y) * y);
-  const gq3 gb = gyp - gq_dot(gyp, x) * x;
-  gx = gx - gq_dot(x, b) * gyp - gq_dot(gyp, x) * b;
-  const gq3 ga = (1.0f / na) * (gx - gq_dot(gx, x) * x);
-  go[3] = ga.x; go[4] = ga.y; go[5] = ga.z;
-  go[6] = gb.x; go[7] = gb.y; go[8] = gb.z;
+  // ---- global pose: fixed-tree sums over the lanes ---------------------------------------------------------------------
+  float tot[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) tot[i] = gq_dpp_sum(acc[i]);
+  if (lane == 0) {
+    gq3 gt = gq_mk(tot[0], tot[1], tot[2]);
+    float gR[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gR[i] = tot[3 + i] + (g.g_R ? g.g_R[(size_t)row * 9 + i] : 0.0f);
+    if (g.g_Rt) {  // grad_t = -R gsum ; grad_R = R K
+      const float* e = g.g_Rt + (size_t)row * 12;
+      gt = gt - gq_mv(R, gq_mk(e[0], e[1], e[2]));
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          gR[i * 3 + j] += R[i * 3 + 0] * e[3 + 0 * 3 + j] + R[i * 3 + 1] * e[3 + 1 * 3 + j] + R[i * 3 + 2] * e[3 + 2 * 3 + j];
+    }
+    go[0] = gt.x; go[1] = gt.y; go[2] = gt.z;
+    // Gram-Schmidt backward: columns of gR are the gradients of x, y, z
+    const gq3 a = gq_mk(hp[3], hp[4], hp[5]), b = gq_mk(hp[6], hp[7], hp[8]);
+    const float na = sqrtf(gq_dot(a, a));
+    const gq3 x = (1.0f / na) * a;
+    const gq3 yp = b - gq_dot(x, b) * x;
+    const float ny = sqrtf(gq_dot(yp, yp));
+    const gq3 y = (1.0f / ny) * yp;
+    gq3 gx = gq_mk(gR[0], gR[3], gR[6]), gy = gq_mk(gR[1], gR[4], gR[7]);
+    const gq3 gz = gq_mk(gR[2], gR[5], gR[8]);
+    gx = gx + gq_cross(y, gz);
+    gy = gy + gq_cross(gz, x);
+    const gq3 gyp = (1.0f / ny) * (gy - gq_dot(gy, y) * y);
+    const gq3 gb = gyp - gq_dot(gyp, x) * x;
+    gx = gx - gq_dot(x, b) * gyp - gq_dot(gyp, x) * b;
+    const gq3 ga = (1.0f / na) * (gx - gq_dot(gx, x) * x);
+    go[3] = ga.x; go[4] = ga.y; go[5] = ga.z;
+    go[6] = gb.x; go[7] = gb.y; go[8] = gb.z;
+  }
 }
 
 // ---- self penetration (hand_model.py:989-1040) ----------------------------------------------------------------------
@@ -361,7 +413,8 @@ extern "C" {
 
 int gq_hand_create(const gqHandDesc* d, gqHand** out) {
   GQ_REQUIRE(d && out, "hand_create: null");
-  GQ_REQUIRE(d->n_dofs > 0 && d->n_dofs <= 64 && d->n_links > 0 && d->n_cand >= 0 && d->n_spheres >= 0,
+  GQ_REQUIRE(d->n_dofs > 0 && d->n_dofs <= 64 && d->n_links > 0 && d->n_links <= 64 && d->n_cand >= 0 &&
+                 d->n_spheres >= 0 && d->n_spheres <= 256,
              "hand_create: bad sizes J=%d L=%d C=%d S=%d", d->n_dofs, d->n_links, d->n_cand, d->n_spheres);
   for (int j = 0; j < d->n_dofs; ++j)
     GQ_REQUIRE(d->node_parent[j] < j && d->node_parent[j] >= -1, "hand_create: node_parent must be topologically sorted");
@@ -399,6 +452,25 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
   rc |= gq_upload(&h->jlo, d->joints_lower, h->J);
   rc |= gq_upload(&h->jhi, d->joints_upper, h->J);
   rc |= gq_upload(&h->group_off, (const int32_t*)groups, (size_t)ng + 1);
+  {
+    int32_t depth[64], coff[65], cidx[64];
+    int md = 0;
+    for (int j = 0; j < h->J; ++j) {
+      depth[j] = d->node_parent[j] < 0 ? 0 : depth[d->node_parent[j]] + 1;
+      md = depth[j] > md ? depth[j] : md;
+    }
+    int k = 0;
+    for (int p = 0; p < h->J; ++p) {
+      coff[p] = k;
+      for (int j = 0; j < h->J; ++j)
+        if (d->node_parent[j] == p) cidx[k++] = j;
+    }
+    coff[h->J] = k;
+    h->max_depth = md;
+    rc |= gq_upload(&h->node_depth, (const int32_t*)depth, h->J);
+    rc |= gq_upload(&h->child_off, (const int32_t*)coff, (size_t)h->J + 1);
+    rc |= gq_upload(&h->child_idx, (const int32_t*)cidx, (size_t)(k > 0 ? k : 1));
+  }
   if (rc) return GQ_ERR_HIP;
   *out = h;
   return GQ_OK;
@@ -407,7 +479,8 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
 int gq_hand_destroy(gqHand* h) {
   if (!h) return GQ_OK;
   void* p[] = {h->node_parent, h->node_type, h->node_pre, h->node_axis, h->link_node, h->link_offset, h->cand_pos,
-               h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off};
+               h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off, h->node_depth,
+               h->child_off, h->child_idx};
   for (void* q : p)
     if (q) (void)hipFree(q);
   delete h;
@@ -441,7 +514,7 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
   a.cpts = contact_points;
   a.cnrm = contact_normals;
   a.spheres = sphere_centers;
-  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }
@@ -472,7 +545,9 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
   a.D = 9 + h->J;
   a.node_F = (float*)workspace + (size_t)batch * h->J * 12;
   a.grad_pose = grad_pose;
-  hipLaunchKernelGGL(gq_fk_backward_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  GQ_REQUIRE(a.n + h->S <= GQ_FK_MAX_ITEMS, "fk_backward: n_contact + n_spheres = %d exceeds %d", a.n + h->S,
+             GQ_FK_MAX_ITEMS);
+  hipLaunchKernelGGL(gq_fk_backward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

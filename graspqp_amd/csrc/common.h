@@ -96,6 +96,16 @@ __device__ __forceinline__ double gq_dpp_sum_d(double v) {
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// plain (NaN-ignoring) min over the wave
+__device__ __forceinline__ float gq_dpp_min(float v) {
+  v = fminf(v, gq_dpp<0xb1, 0xf>(v));
+  v = fminf(v, gq_dpp<0x4e, 0xf>(v));
+  v = fminf(v, gq_dpp<0x114, 0xf>(v));
+  v = fminf(v, gq_dpp<0x118, 0xf>(v));
+  v = fminf(v, gq_dpp<0x142, 0xa>(v));
+  v = fminf(v, gq_dpp<0x143, 0xc>(v));
+  return gq_readlane(v, 63);
+}
 // NaN-propagating min over the wave (torch.min semantics)
 __device__ __forceinline__ float gq_dpp_nanmin(float v) {
   v = gq_nanmin(v, gq_dpp<0xb1, 0xf>(v));

@@ -70,11 +70,12 @@ __global__ __launch_bounds__(256) void gq_qp_stop_kernel(const float* __restrict
   }
 }
 
-// same rule, one wavefront, DPP reductions instead of block barriers (used for B <= 8192)
+// same rule, one wavefront, DPP reductions instead of block barriers, running minima in LDS (used for B <= 8192)
 __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* __restrict__ resid,
                                                                   const float* __restrict__ mu, int B, int max_iter,
                                                                   float eps, int not_improved_lim,
                                                                   float* __restrict__ runmin, int* __restrict__ kstar) {
+  __shared__ float s_run[8192];
   const int lane = gq_lane();
   int not_improved = 0;
   int stop_at = max_iter - 1;
@@ -85,13 +86,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* _
       const float rs = resid[(size_t)r * max_iter + it];
       float bst = rs;
       if (it > 0) {
-        bst = runmin[r];
+        bst = s_run[r];
         if (rs < bst) {
           bst = rs;
           any = true;
         }
       }
-      runmin[r] = bst;
+      s_run[r] = bst;
       mx = gq_nanmax(mx, bst);
       mn = gq_nanmin(mn, mu[(size_t)r * max_iter + it]);
     }

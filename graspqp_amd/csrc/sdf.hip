@@ -80,17 +80,13 @@ __global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
         cmin = c;
       }
     }
-    unsigned long long k = ((unsigned long long)__float_as_uint(lbmin) << 32) | (unsigned)cmin;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long other = __shfl_xor(k, o, GQ_WAVE);
-      k = other < k ? other : k;
+    {
+      const float lbw = gq_dpp_min(lbmin);
+      const unsigned long long who = __ballot(lbmin == lbw);
+      cmin = gq_readlane_i(cmin, who ? __ffsll((long long)who) - 1 : 0);
     }
-    cmin = (int)(k & 0xffffffffu);
     gq_wave_eval_cluster(g.rec, f0 + cmin * 64 + lane, f1, p, best, borig, bi);
-    float ub = best;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ub = fminf(ub, __shfl_xor(ub, o, GQ_WAVE));
+    float ub = gq_dpp_min(best);
     for (int cb = 0; cb < nC; cb += GQ_WAVE) {
       const int c = cb + lane;
       const float lb = (c < nC && c != cmin) ? gq_aabb_dist2(g.cl_aabb + (size_t)(c0 + c) * 8, p) : GQ_INF_F;
@@ -100,21 +96,15 @@ __global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
         mask &= mask - 1;
         if (gq_readlane(lb, s) * 0.9999f > ub) continue;  // ub may have shrunk meanwhile
         gq_wave_eval_cluster(g.rec, f0 + (cb + s) * 64 + lane, f1, p, best, borig, bi);
-        float m = best;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, GQ_WAVE));
-        ub = m;
+        ub = gq_dpp_min(best);
       }
     }
   }
-  unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | borig;
-  unsigned long long kmin = key;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(kmin, o, GQ_WAVE);
-    kmin = other < kmin ? other : kmin;
-  }
-  const unsigned long long win = __ballot(key == kmin && bi >= 0);
+  // winner = smallest distance, then smallest original face index (two DPP min passes)
+  const float dmin = gq_dpp_min(best);
+  const bool tie = (best == dmin) && (bi >= 0);
+  const float omin = gq_dpp_min(tie ? (float)borig : GQ_INF_F);  // face indices < 2^24 are exact in fp32
+  const unsigned long long win = __ballot(tie && (float)borig == omin);
   const int face = win ? gq_readlane_i(bi, __ffsll((long long)win) - 1) : -1;
   if (lane == 0) {
     GqSdfOut o;
@@ -482,6 +472,7 @@ __global__ __launch_bounds__(512) void gq_pen_eval_kernel(GqPenArgs g, GqPenQ q)
 __global__ __launch_bounds__(256) void gq_pen_finalize_kernel(GqPenArgs g, GqPenQ q) {
   const int row = blockIdx.y;
   const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < g.L) q.count[threadIdx.x] = 0;  // ready for the next query
   if (pt < g.P) {
     const size_t o = (size_t)row * g.P + pt;
     const unsigned long long key = q.keys[o];
@@ -534,69 +525,111 @@ struct GqPenBwdArgs {
   float* gRt;     // (B, 12)
 };
 
+// One block per row, surface points in super-chunks of 4096.  Phase A: every thread reads the weights of its 16 points
+// (loads in flight together), the contributing ones (w != 0) are compacted IN POINT ORDER into an LDS list of
+// (link, w*G, x_h) records (ballot prefix inside a wave, (slice, wave) counts across the block) -- the order is
+// independent of scheduling.  Phase B: thread a < L*6 + 12 owns one accumulator and folds the list in order.
+#define GQ_PENB_K 16
+#define GQ_PENB_LIST 4096
 __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
-  extern __shared__ float sm[];  // [4 waves][L*6 + 12]
+  __shared__ float s_rec[GQ_PENB_LIST * 6];
+  __shared__ unsigned char s_lnk[GQ_PENB_LIST];
+  __shared__ int s_cnt[GQ_PENB_K * 4];
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = gq_lane(), wv = tid / GQ_WAVE;
-  const int stride = g.L * 6 + 12;
-  for (int i = tid; i < 4 * stride; i += 256) sm[i] = 0.0f;
-  __syncthreads();
-  float* acc = sm + wv * stride;
   const int obj = row / g.batch_each;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
-  for (int base = 0; base < g.P; base += 256) {
-    const int pt = base + tid;
-    float w = 0.0f;
-    int lk = 0;
-    gq3 G = gq_mk(0, 0, 0), xh = gq_mk(0, 0, 0);
-    if (pt < g.P) {
-      const size_t o = (size_t)row * g.P + pt;
-      w = g.w[o];
-      if (w != 0.0f) {
-        lk = g.link[o];
-        G = w * gq_mk(g.gvec[o * 3], g.gvec[o * 3 + 1], g.gvec[o * 3 + 2]);
+  for (int base = 0; base < g.P; base += GQ_PENB_K * 256) {
+    float w[GQ_PENB_K];
+#pragma unroll
+    for (int k = 0; k < GQ_PENB_K; ++k) {
+      const int pt = base + k * 256 + tid;
+      w[k] = (pt < g.P) ? g.w[(size_t)row * g.P + pt] : 0.0f;
+    }
+    unsigned long long m[GQ_PENB_K];
+#pragma unroll
+    for (int k = 0; k < GQ_PENB_K; ++k) {
+      m[k] = __ballot(w[k] != 0.0f);
+      if (lane == 0) s_cnt[k * 4 + wv] = __popcll(m[k]);
+    }
+    __syncthreads();
+    int run = 0;  // entries before slice k, wave wv
+#pragma unroll
+    for (int k = 0; k < GQ_PENB_K; ++k) {
+      int off = run;
+      for (int q = 0; q < wv; ++q) off += s_cnt[k * 4 + q];
+      run += s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
+      if (w[k] != 0.0f) {
+        const int pt = base + k * 256 + tid;
+        const size_t o = (size_t)row * g.P + pt;
+        const int i = off + __popcll(m[k] & ((1ull << lane) - 1ull));
         const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
-        xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+        const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+        s_rec[i * 6 + 0] = w[k] * g.gvec[o * 3];
+        s_rec[i * 6 + 1] = w[k] * g.gvec[o * 3 + 1];
+        s_rec[i * 6 + 2] = w[k] * g.gvec[o * 3 + 2];
+        s_rec[i * 6 + 3] = xh.x;
+        s_rec[i * 6 + 4] = xh.y;
+        s_rec[i * 6 + 5] = xh.z;
+        s_lnk[i] = (unsigned char)g.link[o];
       }
     }
-    unsigned long long mask = __ballot(w != 0.0f);
-    while (mask) {  // wave-uniform loop over contributing lanes, in lane order
-      const int s = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int l = gq_readlane_i(lk, s);
-      const gq3 Gs = gq_mk(gq_readlane(G.x, s), gq_readlane(G.y, s), gq_readlane(G.z, s));
-      const gq3 xs = gq_mk(gq_readlane(xh.x, s), gq_readlane(xh.y, s), gq_readlane(xh.z, s));
-      const gq3 ms = gq_cross(xs, Gs);
-      if (lane == 0) {
-        float* a = acc + l * 6;
-        a[0] -= Gs.x;
-        a[1] -= Gs.y;
-        a[2] -= Gs.z;
-        a[3] -= ms.x;
-        a[4] -= ms.y;
-        a[5] -= ms.z;
-        float* k = acc + g.L * 6;
-        k[0] += Gs.x;
-        k[1] += Gs.y;
-        k[2] += Gs.z;
-        k[3] += xs.x * Gs.x;
-        k[4] += xs.x * Gs.y;
-        k[5] += xs.x * Gs.z;
-        k[6] += xs.y * Gs.x;
-        k[7] += xs.y * Gs.y;
-        k[8] += xs.y * Gs.z;
-        k[9] += xs.z * Gs.x;
-        k[10] += xs.z * Gs.y;
-        k[11] += xs.z * Gs.z;
+    __syncthreads();
+    const int n = run;  // block-uniform
+    // fold, wave-parallel and in a fixed order: a wavefront takes a group of 4 links (24 accumulators) or the group of
+    // the 12 global sums; lane j adds entries j, j+64, ... into registers, then the fixed DPP tree adds the lanes.
+    //   wrench f_l -= G, m_l -= x_h x G ; gsum += G ; K += x_h (x) G      (G = r[0..2], x_h = r[3..5])
+    const int n_lgroups = (g.L + 3) / 4;
+    for (int grp = wv; grp <= n_lgroups; grp += 4) {  // wave-uniform
+      float part[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) part[q] = 0.0f;
+      const int l0 = grp * 4;
+      for (int i = lane; i < n; i += GQ_WAVE) {
+        const float* r = s_rec + i * 6;
+        const gq3 G = gq_mk(r[0], r[1], r[2]), x = gq_mk(r[3], r[4], r[5]);
+        if (grp < n_lgroups) {
+          const gq3 mm = gq_cross(x, G);
+          const int dl = (int)s_lnk[i] - l0;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float sel = (dl == q4) ? 1.0f : 0.0f;
+            part[q4 * 6 + 0] -= sel * G.x;
+            part[q4 * 6 + 1] -= sel * G.y;
+            part[q4 * 6 + 2] -= sel * G.z;
+            part[q4 * 6 + 3] -= sel * mm.x;
+            part[q4 * 6 + 4] -= sel * mm.y;
+            part[q4 * 6 + 5] -= sel * mm.z;
+          }
+        } else {
+          part[0] += G.x; part[1] += G.y; part[2] += G.z;
+          part[3] += x.x * G.x; part[4] += x.x * G.y; part[5] += x.x * G.z;
+          part[6] += x.y * G.x; part[7] += x.y * G.y; part[8] += x.y * G.z;
+          part[9] += x.z * G.x; part[10] += x.z * G.y; part[11] += x.z * G.z;
+        }
+      }
+      const int nq = (grp < n_lgroups) ? 24 : 12;
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        if (q < nq) {
+          const float tot = gq_dpp_sum(part[q]);
+          if (lane == 0) {
+            if (grp < n_lgroups) {
+              const int l = l0 + q / 6;
+              if (l < g.L) {
+                float* dst = g.wrench + ((size_t)row * g.L + l) * 6 + (q % 6);
+                *dst = (base == 0 ? 0.0f : *dst) + tot;
+              }
+            } else {
+              float* dst = g.gRt + (size_t)row * 12 + q;
+              *dst = (base == 0 ? 0.0f : *dst) + tot;
+            }
+          }
+        }
       }
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < stride; i += 256) {
-    const float v = ((sm[i] + sm[stride + i]) + sm[2 * stride + i]) + sm[3 * stride + i];
-    if (i < g.L * 6) g.wrench[(size_t)row * g.L * 6 + i] = v;
-    else g.gRt[(size_t)row * 12 + (i - g.L * 6)] = v;
+    __syncthreads();
   }
 }
 
@@ -962,7 +995,7 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     q.items = (GqPenItem*)((char*)workspace + 1024);
     q.keys = (unsigned long long*)((char*)workspace + 1024 + cap * sizeof(GqPenItem));
     q.cap_link = (long long)cap_link;
-    GQ_CHECK_HIP(hipMemsetAsync(q.count, 0, sizeof(int) * a.L, (hipStream_t)stream));
+    // q.count is zero on entry: the workspace starts zeroed and gq_pen_finalize_kernel re-zeroes it after use
     hipExtLaunchKernelGGL(gq_pen_scan_kernel, grid, dim3(256), (size_t)a.L * 24 * sizeof(float), (hipStream_t)stream, e0,
                           nullptr, 0, a, q);
     GQ_LAUNCH_CHECK();
@@ -992,7 +1025,7 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
                          void* stream) {
   GQ_REQUIRE(surface_points && hand_pose && Rg && grad_dis && link && gvec && link_wrench && gRt,
              "hand_pen_backward: null");
-  GQ_REQUIRE(n_links > 0 && n_links <= 256 && n_obj > 0 && n_surface > 0 && batch_each > 0, "hand_pen_backward: sizes");
+  GQ_REQUIRE(n_links > 0 && n_links <= 160 && n_obj > 0 && n_surface > 0 && batch_each > 0, "hand_pen_backward: sizes");
   GqPenBwdArgs a{};
   a.surf = surface_points;
   a.hand_pose = hand_pose;
@@ -1007,8 +1040,7 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
   a.batch_each = (int)batch_each;
   a.wrench = link_wrench;
   a.gRt = gRt;
-  const size_t shm = (size_t)4 * (n_links * 6 + 12) * sizeof(float);
-  hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), shm, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -412,7 +412,7 @@ class _HandPen(torch.autograd.Function):
         pws, pnb = None, 0
         if int(penetration_only) == 1:
             pnb = _size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), hand.L)
-            pws = _ws(pnb, dev)
+            pws = torch.zeros(pnb, dtype=torch.uint8, device=dev)  # queue counters must start at zero
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
                 _C.f32(Rg), _C.f32(LT), int(penetration_only), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.ptr(pws), pnb,
                 None, None, _C.stream_ptr())

@@ -84,7 +84,7 @@ class GraspStepper:
                                     int(self.fc["max_iter"]))
         self.fc_ws = ops._ws(self.fc_nb, self.dev)
         self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
-        self.pen_ws = ops._ws(self.pen_nb, self.dev)
+        self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)  # queue counters start at zero
         self._graph = None
         self.kernel_events = None
         self._span = None

@@ -131,7 +131,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
                         int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                         const float* link_T, int penetration_only, float* dis, int32_t* link, float* gvec,
-                        void* workspace /* NULL, or gq_hand_pen_workspace_bytes: enables the load-balanced path */,
+                        void* workspace /* NULL, or gq_hand_pen_workspace_bytes (ZEROED before first use): load-balanced path */,
                         size_t workspace_bytes, void* timer /* gqTimer or NULL */,
                         uint64_t* span /* NULL, or {min start, max end} in 100 MHz device ticks, pre-set to {~0, 0} */,
                         void* stream);

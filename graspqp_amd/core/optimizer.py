@@ -57,7 +57,7 @@ class MalaStar:
         _C.call("gq_mala_propose", _C.f32(hp), _C.f32(grad), _C.i64(idx), _C.f32(u_switch.contiguous()),
                 _C.i64(new_idx.contiguous()), B, D, n, self.step_size, self.step_size_period, self.temperature_decay,
                 self.mu, self.switch_possibility, int(self.clip_grad), _C.f32(self.ema_grad_hand_pose), _C.i64(self.step),
-                _C.f32(pose_out), _C.i64(idx_out), _C.f32(s), _C.f32(self._g2), _C.stream_ptr())
+                _C.f32(pose_out), _C.i64(idx_out), _C.f32(s), _C.f32(self._g2), None, 0, None, _C.stream_ptr())
         self.old_hand_pose = hp
         self.old_contact_point_indices = idx
         self.old_grad_hand_pose = grad

@@ -5,6 +5,14 @@
 // constants for autograd, object_model.py:246).
 #include "common.h"
 
+int gq_lsq_boxqp_iterate_(const float* A, float lower_s, float upper_s, int64_t batch, int m, int nz, float ridge,
+                          float eps, int max_iter, int32_t* n_iter, void* workspace, size_t workspace_bytes,
+                          void* stream, const float** resid, const float** snap, const int** kstar);
+int gq_lsq_boxqp_backward_scaled_(const float* A, const float* lam, const float* slack, const float* grad_x,
+                                  int64_t batch, int m, int nz, float ridge, float* dx, float* dlam,
+                                  const float* scale_ge, const float* scale_svd, float svd_gain, float values_gain,
+                                  void* stream);
+
 struct GqCone {
   gq3 f;    // cone edge (already divided by k)
   gq3 tau;  // torque_weight * (r x f)
@@ -83,7 +91,13 @@ __device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21]) {
 
 struct GqFcArgs {
   const float* F;     // (B,6,nz)
-  const float* x;     // (B,nz)
+  float* x;           // (B,nz)   written here from the best PDIPM snapshot (select fused in)
+  float* lam;         // (B,2nz)
+  float* slack;       // (B,2nz)
+  const float* resid; // (B,max_iter)
+  const float* snap;  // (B,max_iter,5,nz)
+  const int* kstar;
+  int max_iter;
   int B, n, k;
   float svd_gain, values_gain, eps_add;
   float* e_fc;   // (B)
@@ -96,6 +110,20 @@ struct GqFcArgs {
 __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
   const int row = blockIdx.x, lane = gq_lane();
   const int nz = g.n * g.k;
+  // best iterate of this row among iterations 0..k* (qpth returns the per-row best, not the last)
+  int bi = 0;
+  {
+    const int ks = g.kstar[0];
+    float bst = 0.0f;
+    for (int it = 0; it <= ks; ++it) {
+      const float rs = g.resid[(size_t)row * g.max_iter + it];
+      if (it == 0 || rs < bst) {
+        bst = rs;
+        bi = it;
+      }
+    }
+  }
+  const float* sn = g.snap + (((size_t)row * g.max_iter + bi) * 5) * nz;
   double gr[21];
 #pragma unroll
   for (int i = 0; i < 21; ++i) gr[i] = 0.0;
@@ -105,7 +133,12 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
     float f[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) f[q] = g.F[((size_t)row * 6 + q) * nz + i];
-    const float xi = g.x[(size_t)row * nz + i];
+    const float xi = sn[i];
+    g.x[(size_t)row * nz + i] = xi;
+    g.lam[(size_t)row * 2 * nz + i] = sn[nz + i];
+    g.lam[(size_t)row * 2 * nz + nz + i] = sn[2 * nz + i];
+    g.slack[(size_t)row * 2 * nz + i] = sn[3 * nz + i];
+    g.slack[(size_t)row * 2 * nz + nz + i] = sn[4 * nz + i];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       r[a] = fmaf(f[a], xi, r[a]);
@@ -136,7 +169,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
   if (g.x_sum) {
     for (int c = lane; c < g.n; c += GQ_WAVE) {
       float s = 0.0f;
-      for (int e = 0; e < g.k; ++e) s += g.x[(size_t)row * nz + c * g.k + e];
+      for (int e = 0; e < g.k; ++e) s += sn[c * g.k + e];
       g.x_sum[(size_t)row * g.n + c] = s;
     }
   }
@@ -169,6 +202,7 @@ struct GqFcBwdArgs {
   const float* svd;
   int B, n, k;
   float mu, tw, svd_gain, values_gain, eps_add;
+  int accumulate;  // add into g_cpts instead of overwriting
   float* g_cpts;  // (B,n,3)
 };
 
@@ -247,9 +281,15 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
       sz += sh[(c * g.k + e) * 3 + 2];
     }
     float* o = g.g_cpts + ((size_t)row * g.n + c) * 3;
-    o[0] = sx;
-    o[1] = sy;
-    o[2] = sz;
+    if (g.accumulate) {
+      o[0] += sx;
+      o[1] += sy;
+      o[2] += sz;
+    } else {
+      o[0] = sx;
+      o[1] = sy;
+      o[2] = sz;
+    }
   }
 }
 
@@ -311,12 +351,20 @@ int gq_fc_forward(const float* contact_pts, const float* contact_normals, const 
                      contact_normals, cog, (int)batch, n_contact, n_cone, friction, torque_weight, w.F);
   GQ_LAUNCH_CHECK();
   // bounds 1 <= x <= max_limit + 1, b = 0, ridge 1e-4 (span.py:348-349, qp_solver.py:101-112)
-  rc = gq_lsq_boxqp_forward(w.F, nullptr, nullptr, nullptr, 1.0f, max_limit + 1.0f, batch, 6, nz, 1e-4f, eps,
-                            max_iter, 3, w.x, w.lam, w.slack, nullptr, n_iter, w.qp, w.qp_bytes, stream);
+  const float *resid = nullptr, *snap = nullptr;
+  const int* kstar = nullptr;
+  rc = gq_lsq_boxqp_iterate_(w.F, 1.0f, max_limit + 1.0f, batch, 6, nz, 1e-4f, eps, max_iter, n_iter, w.qp, w.qp_bytes,
+                             stream, &resid, &snap, &kstar);
   if (rc) return rc;
   GqFcArgs a{};
   a.F = w.F;
   a.x = w.x;
+  a.lam = w.lam;
+  a.slack = w.slack;
+  a.resid = resid;
+  a.snap = snap;
+  a.kstar = kstar;
+  a.max_iter = max_iter;
   a.B = (int)batch;
   a.n = n_contact;
   a.k = n_cone;
@@ -336,17 +384,17 @@ int gq_fc_forward(const float* contact_pts, const float* contact_normals, const 
 // Gradient of E_fc wrt contact_pts for upstream grad_e (B,); must follow gq_fc_forward on the same workspace.
 int gq_fc_backward(const float* contact_pts, const float* contact_normals, const float* cog, const float* grad_e,
                    int64_t batch, int n_contact, int n_cone, float friction, float torque_weight, float svd_gain,
-                   float values_gain, float* grad_contact_pts, void* workspace, size_t workspace_bytes, void* stream) {
+                   float values_gain, int accumulate, float* grad_contact_pts, void* workspace, size_t workspace_bytes,
+                   void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GQ_REQUIRE(contact_pts && contact_normals && cog && grad_e && grad_contact_pts && workspace, "fc_backward: null");
   GQ_REQUIRE(batch > 0 && n_contact > 0 && n_cone > 0, "fc_backward: bad sizes");
   const int nz = n_contact * n_cone;
   GqFcWs w = gq_fc_carve(workspace, (size_t)batch, (size_t)nz, workspace_bytes);
-  const int64_t tot = batch * nz;
-  hipLaunchKernelGGL(gq_fc_dldx_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, grad_e, w.svd, w.Ftr,
-                     (int)batch, nz, svd_gain, values_gain, w.dldx);
-  GQ_LAUNCH_CHECK();
-  int rc = gq_lsq_boxqp_backward(w.F, w.lam, w.slack, w.dldx, batch, 6, nz, 1e-4f, w.dx, w.dlam, stream);
+  // dl/dx = g_val * F'(F x) with g_val = g_e * values_gain * exp(-svd_gain * svd): the scale is applied inside the
+  // QP backward kernel (no separate elementwise launch)
+  int rc = gq_lsq_boxqp_backward_scaled_(w.F, w.lam, w.slack, w.Ftr, batch, 6, nz, 1e-4f, w.dx, w.dlam, grad_e, w.svd,
+                                         svd_gain, values_gain, stream);
   if (rc) return rc;
   GqFcBwdArgs a{};
   a.F = w.F;
@@ -366,6 +414,7 @@ int gq_fc_backward(const float* contact_pts, const float* contact_normals, const
   a.svd_gain = svd_gain;
   a.values_gain = values_gain;
   a.eps_add = 1e-2f;
+  a.accumulate = accumulate;
   a.g_cpts = grad_contact_pts;
   hipLaunchKernelGGL(gq_fc_grad_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), (size_t)nz * 3 * sizeof(float), st, a);
   GQ_LAUNCH_CHECK();

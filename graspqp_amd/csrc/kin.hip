@@ -347,13 +347,17 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
 // one link), finds each group's most penetrating pair against all LATER groups, then lane q == 0 folds the groups
 // in order (bitwise reproducible) into the energy and the centre gradients.
 __global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* __restrict__ centers, int B,
-                                                         float* __restrict__ e_spen, float* __restrict__ g_centers) {
+                                                         float gscale, float* __restrict__ e_spen,
+                                                         float* __restrict__ g_centers) {
   __shared__ float s_pen[4][64];
   __shared__ int s_a[4][64], s_b[4][64];
+  __shared__ float s_c[4][256 * 3];
   const int r4 = threadIdx.x >> 4, q = threadIdx.x & 15;
   const int row = blockIdx.x * 4 + r4;
   const bool ok = row < B;
-  const float* c = centers + (size_t)(ok ? row : 0) * h.S * 3;
+  for (int i = q; i < h.S * 3; i += 16) s_c[r4][i] = centers[(size_t)(ok ? row : 0) * h.S * 3 + i];
+  __syncthreads();
+  const float* c = s_c[r4];
   const int ng = h.NG - 1;  // the last group has nothing after it
   for (int gi = q; gi < ng && gi < 64; gi += 16) {
     const int a0 = h.group_off[gi], a1 = h.group_off[gi + 1];
@@ -392,8 +396,9 @@ __global__ __launch_bounds__(64) void gq_self_pen_kernel(gqHand h, const float* 
                           c[ba * 3 + 2] - c[bb * 3 + 2] + 1e-13f);
       const float inv = 1.0f / sqrtf(gq_dot(d, d));
       // E += -|a-b| + ... : dE/da = -(a-b)/|a-b|, dE/db = +(a-b)/|a-b|
-      gc[ba * 3] -= d.x * inv; gc[ba * 3 + 1] -= d.y * inv; gc[ba * 3 + 2] -= d.z * inv;
-      gc[bb * 3] += d.x * inv; gc[bb * 3 + 1] += d.y * inv; gc[bb * 3 + 2] += d.z * inv;
+      const float sc = gscale * inv;
+      gc[ba * 3] -= d.x * sc; gc[ba * 3 + 1] -= d.y * sc; gc[ba * 3 + 2] -= d.z * sc;
+      gc[bb * 3] += d.x * sc; gc[bb * 3 + 1] += d.y * sc; gc[bb * 3 + 2] += d.z * sc;
     }
   }
   e_spen[row] = e;
@@ -552,11 +557,11 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
   return GQ_OK;
 }
 
-int gq_self_pen_forward(const gqHand* h, const float* sphere_centers, int64_t batch, float* e_spen, float* g_centers,
-                        void* stream) {
+int gq_self_pen_forward(const gqHand* h, const float* sphere_centers, int64_t batch, float grad_scale, float* e_spen,
+                        float* g_centers, void* stream) {
   GQ_REQUIRE(h && sphere_centers && e_spen && g_centers && batch > 0, "self_pen_forward: bad arguments");
   hipLaunchKernelGGL(gq_self_pen_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, (hipStream_t)stream, *h,
-                     sphere_centers, (int)batch, e_spen, g_centers);
+                     sphere_centers, (int)batch, grad_scale, e_spen, g_centers);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

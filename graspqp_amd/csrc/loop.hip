@@ -186,6 +186,9 @@ struct GqProposeArgs {
   float* pose_out;  // (B,D)
   int64_t* idx_out; // (B,n)
   float* s_out;     // (B) or null
+  const float* energy;  // (B) accepted energies or null
+  int batch_each;
+  float* z_out;     // (B) per-object z-score of `energy` (fit.py:403-406), written when energy != null
 };
 
 // one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
@@ -225,6 +228,19 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_mala_propose_kernel(GqProposeArgs 
   if (lane == 0) {
     g.step[row] = st + 1;
     if (g.s_out) g.s_out[row] = s;
+  }
+  if (g.energy) {  // z = (E - mean_obj) / std_obj (unbiased) over the rows of this row's object
+    const float* e = g.energy + (size_t)(row / g.batch_each) * g.batch_each;
+    float acc = 0.0f;
+    for (int i = lane; i < g.batch_each; i += GQ_WAVE) acc += e[i];
+    const float mean = gq_dpp_sum(acc) / (float)g.batch_each;
+    acc = 0.0f;
+    for (int i = lane; i < g.batch_each; i += GQ_WAVE) {
+      const float d = e[i] - mean;
+      acc = fmaf(d, d, acc);
+    }
+    const float sd = sqrtf(gq_dpp_sum(acc) / (float)(g.batch_each - 1));
+    if (lane == 0) g.z_out[row] = (g.energy[row] - mean) / sd;
   }
 }
 
@@ -408,7 +424,7 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
                     const int64_t* new_idx, int64_t batch, int pose_dim, int n_contact, float step_size,
                     int stepsize_period, float decay, float mu, float switch_possibility, int clip_grad, float* ema,
                     int64_t* step, float* pose_out, int64_t* idx_out, float* step_size_out, float* g2_scratch,
-                    void* stream) {
+                    const float* energy, int64_t batch_each, float* z_out, void* stream) {
   GQ_REQUIRE(hand_pose && grad && contact_idx && u_switch && new_idx && ema && step && pose_out && idx_out &&
                  g2_scratch && batch > 0 && pose_dim > 9 && pose_dim <= 128 && n_contact > 0 && stepsize_period > 0,
              "mala_propose: bad arguments");
@@ -437,6 +453,11 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
   a.pose_out = pose_out;
   a.idx_out = idx_out;
   a.s_out = step_size_out;
+  GQ_REQUIRE(energy == nullptr || (z_out != nullptr && batch_each > 0 && batch % batch_each == 0),
+             "mala_propose: z-score needs z_out and batch_each dividing batch");
+  a.energy = energy;
+  a.batch_each = (int)batch_each;
+  a.z_out = z_out;
   hipLaunchKernelGGL(gq_mala_propose_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, st, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;

@@ -13,7 +13,8 @@
 // ---- batch-global stopping rule (single block) -----------------------------------------------------------
 __global__ __launch_bounds__(256) void gq_qp_stop_kernel(const float* __restrict__ resid, const float* __restrict__ mu,
                                                          int B, int max_iter, float eps, int not_improved_lim,
-                                                         float* __restrict__ runmin, int* __restrict__ kstar) {
+                                                         float* __restrict__ runmin, int* __restrict__ kstar,
+                                                         int* __restrict__ n_iter_out) {
   __shared__ int s_any;
   __shared__ float s_red[256];
   __shared__ float s_red2[256];
@@ -67,34 +68,52 @@ __global__ __launch_bounds__(256) void gq_qp_stop_kernel(const float* __restrict
   if (tid == 0) {
     kstar[0] = stop_at;      // last iteration whose record counts
     kstar[1] = stop_at + 1;  // qpth-style iteration count
+    if (n_iter_out) *n_iter_out = stop_at + 1;
   }
 }
 
-// same rule, one wavefront, DPP reductions instead of block barriers, running minima in LDS (used for B <= 8192)
+// same rule, one wavefront (B <= 1024): the (B, max_iter) residual / mu tables are staged in LDS with all loads in
+// flight at once, then replayed iteration by iteration with DPP reductions -- no block barriers, no dependent global
+// round trips.
+#define GQ_STOP_MAXB 1024
+#define GQ_STOP_MAXIT 16
 __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* __restrict__ resid,
                                                                   const float* __restrict__ mu, int B, int max_iter,
                                                                   float eps, int not_improved_lim,
-                                                                  float* __restrict__ runmin, int* __restrict__ kstar) {
-  __shared__ float s_run[8192];
+                                                                  float* __restrict__ runmin, int* __restrict__ kstar,
+                                                                  int* __restrict__ n_iter_out) {
+  __shared__ float s_res[GQ_STOP_MAXB * GQ_STOP_MAXIT];
+  __shared__ float s_mu[GQ_STOP_MAXB * GQ_STOP_MAXIT];
   const int lane = gq_lane();
+  const int tot = B * max_iter;
+  for (int i = lane; i < tot; i += GQ_WAVE) {
+    s_res[i] = resid[i];
+    s_mu[i] = mu[i];
+  }
+  __syncthreads();
   int not_improved = 0;
   int stop_at = max_iter - 1;
+  float run[GQ_STOP_MAXB / GQ_WAVE];  // running best residual of my rows (lane, lane+64, ...)
   for (int it = 0; it < max_iter; ++it) {
     float mx = -GQ_INF, mn = GQ_INF;
     bool any = false;
-    for (int r = lane; r < B; r += GQ_WAVE) {
-      const float rs = resid[(size_t)r * max_iter + it];
-      float bst = rs;
-      if (it > 0) {
-        bst = s_run[r];
-        if (rs < bst) {
-          bst = rs;
-          any = true;
+#pragma unroll
+    for (int k = 0; k < GQ_STOP_MAXB / GQ_WAVE; ++k) {
+      const int r = lane + GQ_WAVE * k;
+      if (r < B) {
+        const float rs = s_res[r * max_iter + it];
+        float bst = rs;
+        if (it > 0) {
+          bst = run[k];
+          if (rs < bst) {
+            bst = rs;
+            any = true;
+          }
         }
+        run[k] = bst;
+        mx = gq_nanmax(mx, bst);
+        mn = gq_nanmin(mn, s_mu[r * max_iter + it]);
       }
-      s_run[r] = bst;
-      mx = gq_nanmax(mx, bst);
-      mn = gq_nanmin(mn, mu[(size_t)r * max_iter + it]);
     }
     const bool any_w = __ballot(any) != 0ull;
     const float mxw = -gq_dpp_nanmin(-mx);  // NaN-propagating max
@@ -108,6 +127,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* _
   if (lane == 0) {
     kstar[0] = stop_at;
     kstar[1] = stop_at + 1;
+    if (n_iter_out) *n_iter_out = stop_at + 1;
   }
 }
 
@@ -187,7 +207,7 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
   GQ_REQUIRE(a.nz <= (mode == 0 ? 128 : 64), "boxqp: nz=%d exceeds the supported size (%d)", a.nz, mode == 0 ? 128 : 64);
   GQ_REQUIRE(a.max_iter >= 1 && a.max_iter <= 64, "boxqp: max_iter=%d out of range", a.max_iter);
   GQ_REQUIRE(mode == 1 || (a.m >= 1 && a.m <= 8), "boxqp: m=%d must be in [1,8]", a.m);
-  GQ_REQUIRE(x && lam && slack && ws, "boxqp: null output/workspace pointer");
+  GQ_REQUIRE(ws, "boxqp: null workspace pointer");
   GqQpWs w = gq_qp_carve(ws, a.B, a.nz, a.max_iter);
   GQ_REQUIRE(ws_bytes >= w.total, "boxqp: workspace too small (%zu < %zu)", ws_bytes, w.total);
   a.resid = w.resid;
@@ -195,18 +215,63 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
   a.snap = w.snap;
   int rc = gq_launch_iter(a, mode, st);
   if (rc) return rc;
-  if (a.B <= 8192)
+  if (a.B <= GQ_STOP_MAXB && a.max_iter <= GQ_STOP_MAXIT)
     hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
-                       not_improved_lim, w.runmin, w.kstar);
+                       not_improved_lim, w.runmin, w.kstar, n_iter);
   else
     hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
-                       not_improved_lim, w.runmin, w.kstar);
+                       not_improved_lim, w.runmin, w.kstar, n_iter);
   GQ_LAUNCH_CHECK();
+  if (x == nullptr) return GQ_OK;  // internal callers (fc.hip) select the best iterate inside their own kernel
   hipLaunchKernelGGL(gq_qp_select_kernel, dim3(a.B), dim3(GQ_WAVE), 0, st, w.resid, w.snap, w.kstar, a.B, a.nz,
                      a.max_iter, x, lam, slack, best_iter);
   GQ_LAUNCH_CHECK();
-  if (n_iter) GQ_CHECK_HIP(hipMemcpyAsync(n_iter, w.kstar + 1, sizeof(int), hipMemcpyDeviceToDevice, st));
   return GQ_OK;
+}
+
+// internal (fc.hip): run the iterations and the stop rule only; the caller picks each row's best iterate itself
+int gq_lsq_boxqp_iterate_(const float* A, float lower_s, float upper_s, int64_t batch, int m, int nz, float ridge,
+                          float eps, int max_iter, int32_t* n_iter, void* workspace, size_t workspace_bytes,
+                          void* stream, const float** resid, const float** snap, const int** kstar) {
+  GqQpArgs a{};
+  a.A = A;
+  a.lower_s = lower_s;
+  a.upper_s = upper_s;
+  a.ridge = ridge;
+  a.B = (int)batch;
+  a.m = m;
+  a.nz = nz;
+  a.max_iter = max_iter;
+  int rc = gq_qp_forward_common(a, eps, 3, nullptr, nullptr, nullptr, nullptr, n_iter, workspace, workspace_bytes,
+                                (hipStream_t)stream, 0);
+  if (rc) return rc;
+  GqQpWs w = gq_qp_carve(workspace, a.B, a.nz, a.max_iter);
+  *resid = w.resid;
+  *snap = w.snap;
+  *kstar = w.kstar;
+  return GQ_OK;
+}
+
+int gq_lsq_boxqp_backward_scaled_(const float* A, const float* lam, const float* slack, const float* grad_x,
+                                  int64_t batch, int m, int nz, float ridge, float* dx, float* dlam,
+                                  const float* scale_ge, const float* scale_svd, float svd_gain, float values_gain,
+                                  void* stream) {
+  GqQpBwdArgs a{};
+  a.A = A;
+  a.lam = lam;
+  a.slack = slack;
+  a.grad_x = grad_x;
+  a.ridge = ridge;
+  a.B = (int)batch;
+  a.m = m;
+  a.nz = nz;
+  a.dx = dx;
+  a.dlam = dlam;
+  a.scale_ge = scale_ge;
+  a.scale_svd = scale_svd;
+  a.svd_gain = svd_gain;
+  a.values_gain = values_gain;
+  return gq_launch_bwd(a, 0, (hipStream_t)stream);
 }
 
 extern "C" {

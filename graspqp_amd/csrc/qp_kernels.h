@@ -144,6 +144,10 @@ struct GqQpBwdArgs {
   int B, m, nz;
   float* dx;    // (B, nz)  = grad wrt p
   float* dlam;  // (B, 2nz) ; grad wrt h = -dlam
+  // optional per-row scale of grad_x (fc energy: grad_x = Ftr, scale = g_e * values_gain * exp(-svd_gain * svd))
+  const float* scale_ge;
+  const float* scale_svd;
+  float svd_gain, values_gain;
 };
 
 template <int NZ, int MODE>

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_lr_bwd_kernel(GqQpBwdArgs g) {
   S.ridge = g.ridge;
   bool live[NC];
   float du[NC], dl[NC], lam[NC], rhs[NC], dx[NC];
+  const float gscale = g.scale_ge ? g.scale_ge[row] * g.values_gain * expf(-g.svd_gain * g.scale_svd[row]) : 1.0f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int k = lane + GQ_WAVE * c;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_lr_bwd_kernel(GqQpBwdArgs g) {
       const float* sk = g.slack + (size_t)row * 2 * nz;
       du[c] = fmaxf(lm[k], 1e-8f) / fmaxf(sk[k], 1e-8f);
       dl[c] = fmaxf(lm[nz + k], 1e-8f) / fmaxf(sk[nz + k], 1e-8f);
-      rhs[c] = -g.grad_x[(size_t)row * nz + k];
+      rhs[c] = -gscale * g.grad_x[(size_t)row * nz + k];
     }
     lam[c] = g.ridge + du[c] + dl[c];
   }

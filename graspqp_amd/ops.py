@@ -267,7 +267,7 @@ class _FcEnergy(torch.autograd.Function):
         B, n, _ = cp.shape
         gp = torch.empty_like(cp)
         _C.call("gq_fc_backward", _C.f32(cp), _C.f32(cn), _C.f32(cg), _C.f32(_c(ge)), B, n, int(cfg["n_cone_vecs"]),
-                float(cfg["friction"]), float(cfg["torque_weight"]), float(cfg["svd_gain"]), float(cfg["values_gain"]),
+                float(cfg["friction"]), float(cfg["torque_weight"]), float(cfg["svd_gain"]), float(cfg["values_gain"]), 0,
                 _C.f32(gp), _C.ptr(ws), ctx.nb, _C.stream_ptr())
         return gp, None, None, None
 
@@ -446,7 +446,7 @@ class _SelfPen(torch.autograd.Function):
         B = c.shape[0]
         e = torch.empty(B, device=c.device)
         g = torch.empty_like(c)
-        _C.call("gq_self_pen_forward", hand.handle, _C.f32(c), B, _C.f32(e), _C.f32(g), _C.stream_ptr())
+        _C.call("gq_self_pen_forward", hand.handle, _C.f32(c), B, 1.0, _C.f32(e), _C.f32(g), _C.stream_ptr())
         ctx.save_for_backward(g)
         return e
 

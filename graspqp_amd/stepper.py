@@ -77,6 +77,10 @@ class GraspStepper:
         self.g2 = f(D)
         self.u_switch, self.u_accept = f(B, n), f(B)
         self.new_idx = torch.zeros(B, n, dtype=torch.long, device=self.dev)
+        self._u_sw, self._u_ac = f(64, B, n), f(64, B)
+        self._n_ix = torch.zeros(64, B, n, dtype=torch.long, device=self.dev)
+        self._draw_pos = 0
+        self._cur = (self.u_switch, self.new_idx, self.u_accept)
         self.n_iter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.x_sum = f(B, n)
         self.fk_ws, self.fk_nb = hand.fk_ws(B, self.dev)
@@ -120,8 +124,8 @@ class GraspStepper:
         C, f32, i32, i64 = _C.call, _C.f32, _C.i32, _C.i64
         e_dis, e_fc, e_pen, e_spen, e_joints = (self.terms_new[i] for i in range(5))
         if self.S > 0:
-            C("gq_self_pen_forward", self.hand.handle, f32(self.spheres), B, f32(e_spen), f32(self.g_sph), st)
-            C("gq_scale", f32(self.g_sph_w), f32(self.g_sph), float(w["E_spen"]), B * self.S * 3, st)
+            C("gq_self_pen_forward", self.hand.handle, f32(self.spheres), B, float(w["E_spen"]), f32(e_spen),
+              f32(self.g_sph_w), st)
         else:
             C("gq_fill", f32(e_spen), 0.0, B, st)
         C("gq_row_energy", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.cnrm), f32(pose), f32(self.jlo),
@@ -131,8 +135,7 @@ class GraspStepper:
         # backward
         C("gq_fc_backward", f32(self.cpts), f32(self.obj_normal), f32(self.cog), f32(self.w_fc_vec), B, n,
           int(fc["n_cone_vecs"]), float(fc["friction"]), float(fc["torque_weight"]), float(fc["svd_gain"]),
-          float(fc["values_gain"]), f32(self.g_cpts_fc), _C.ptr(self.fc_ws), self.fc_nb, st)
-        C("gq_axpy", f32(self.g_cpts), f32(self.g_cpts_fc), 1.0, B * n * 3, st)
+          float(fc["values_gain"]), 1, f32(self.g_cpts), _C.ptr(self.fc_ws), self.fc_nb, st)
         C("gq_hand_pen_backward", self.L, f32(self.surf), self.n_obj, P, self.be, f32(pose), self.D, f32(self.Rg),
           f32(self.g_pen), i32(self.pen_link), f32(self.pen_gvec), f32(self.wrench), f32(self.gRt), st)
         C("gq_fk_backward", self.hand.handle, f32(pose), i64(idx), B, n, f32(self.Rg), f32(self.link_T), f32(self.g_cpts),
@@ -164,30 +167,41 @@ class GraspStepper:
         self.step_count.zero_()
 
     def draw(self):
-        """Random draws of one iteration (optimizer.py:253-257,305); full-size randint + select, no host sync."""
-        self.u_switch.uniform_(generator=self.gen)
-        self.new_idx.random_(0, self.hand.spec.n_contact_candidates, generator=self.gen)
-        self.u_accept.uniform_(generator=self.gen)
+        """Random draws of one iteration (optimizer.py:253-257,305): full-size draws + select (no host sync),
+        generated 64 iterations at a time and sliced per iteration (3 generator launches per 64 iterations)."""
+        k = self._draw_pos
+        if k == 0:
+            self._u_sw.uniform_(generator=self.gen)
+            self._n_ix.random_(0, self.hand.spec.n_contact_candidates, generator=self.gen)
+            self._u_ac.uniform_(generator=self.gen)
+        self._cur = (self._u_sw[k], self._n_ix[k], self._u_ac[k])
+        self._draw_pos = (k + 1) % 64
 
-    def _step_head(self, st):
+    def _propose(self, st):
+        """MalaStar.try_step + z-score of the old energies; launched eagerly so that it can read this iteration's slice
+        of the pre-generated random draws directly (no copy)."""
         B, D, n, m = self.B, self.D, self.n, self.mala
         C, f32, i64 = _C.call, _C.f32, _C.i64
-        C("gq_mala_propose", f32(self.hand_pose), f32(self.grad), i64(self.contact_idx), f32(self.u_switch),
-          i64(self.new_idx), B, D, n, float(m["step_size"]), int(m["stepsize_period"]), float(m["temperature_decay"]),
+        C("gq_mala_propose", f32(self.hand_pose), f32(self.grad), i64(self.contact_idx), f32(self._cur[0]),
+          i64(self._cur[1]), B, D, n, float(m["step_size"]), int(m["stepsize_period"]), float(m["temperature_decay"]),
           float(m["mu"]), float(m["switch_possibility"]), int(bool(m["clip_grad"])), f32(self.ema), i64(self.step_count),
-          f32(self.pose_new), i64(self.idx_new), f32(self.s_out), f32(self.g2), st)
-        C("gq_zscore", f32(self.energy), self.n_obj, self.be, f32(self.z), st)  # z-score of the OLD energies
-        self._eval_pre(self.pose_new, self.idx_new, st)
+          f32(self.pose_new), i64(self.idx_new), f32(self.s_out), f32(self.g2), f32(self.energy), self.be, f32(self.z),
+          st)  # the z-score of the OLD energies (fit.py:403-406) rides in the same launch
 
-    def _step_tail(self, st):
+    def _accept(self, st):
         B, D, n, m = self.B, self.D, self.n, self.mala
         C, f32, i64 = _C.call, _C.f32, _C.i64
-        self._eval_post(self.pose_new, self.idx_new, st)
-        C("gq_mala_accept", f32(self.total_new), f32(self.u_accept), f32(self.z), None,
+        C("gq_mala_accept", f32(self.total_new), f32(self._cur[2]), f32(self.z), None,
           i64(self.step_count), f32(self.pose_new), i64(self.idx_new), f32(self.grad_new), B, D, n,
           float(m["starting_temperature"]), float(m["temperature_decay"]), int(m["annealing_period"]), f32(self.energy),
           f32(self.hand_pose), i64(self.contact_idx), f32(self.grad), _C.u8(self.accept), f32(self.temperature), 5,
           f32(self.terms_new), f32(self.terms), st)
+
+    def _step_head(self, st):
+        self._eval_pre(self.pose_new, self.idx_new, st)
+
+    def _step_tail(self, st):
+        self._eval_post(self.pose_new, self.idx_new, st)
 
     def _pen_timed(self, st):
         ev = self.kernel_events
@@ -235,7 +249,9 @@ class GraspStepper:
             self.u_switch.copy_(draws[0])
             self.new_idx.copy_(draws[1])
             self.u_accept.copy_(draws[2])
+            self._cur = (self.u_switch, self.new_idx, self.u_accept)
         st = _C.stream_ptr()
+        self._propose(st)
         if self._graph is not None:
             self._graph[0].replay()
             self._pen_timed(st)
@@ -244,20 +260,25 @@ class GraspStepper:
             self._step_head(st)
             self._pen_timed(st)
             self._step_tail(st)
+        self._accept(st)
 
     def capture(self):
-        """Capture one iteration into two hipGraphs (everything before / after the hand-penetration kernel, which
-        stays an ordinary launch so it can be bracketed by events).  The state is saved and restored around the
-        warm-up + capture passes, so capturing does not advance the chain."""
+        """Capture the energy + gradient evaluation of one iteration into two hipGraphs (the launches before / after the
+        hand-penetration query).  Propose, the penetration query and accept stay ordinary launches: the first and last
+        read the current slice of the pre-generated random numbers, the middle one is timed by bench.py.  The state is
+        saved and restored around the warm-up + capture passes, so capturing does not advance the chain."""
         saved = [t.clone() for t in (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema,
                                      self.step_count, self.terms)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        self.draw()
         with torch.cuda.stream(s):
             st = _C.stream_ptr()
+            self._propose(st)
             self._step_head(st)
             self._eval_pen(self.pose_new, st)
             self._step_tail(st)
+            self._accept(st)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

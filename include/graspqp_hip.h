@@ -82,7 +82,8 @@ int gq_fc_forward(const float* contact_pts, const float* contact_normals, const 
                   void* stream);
 int gq_fc_backward(const float* contact_pts, const float* contact_normals, const float* cog, const float* grad_e,
                    int64_t batch, int n_contact, int n_cone, float friction, float torque_weight, float svd_gain,
-                   float values_gain, float* grad_contact_pts, void* workspace, size_t workspace_bytes, void* stream);
+                   float values_gain, int accumulate /* 1: grad_contact_pts += */, float* grad_contact_pts,
+                   void* workspace, size_t workspace_bytes, void* stream);
 int gq_fc_peek(void* workspace, size_t workspace_bytes, int64_t batch, int n_contact, int n_cone, const float** F,
                const float** x, const float** val, const float** svd);
 
@@ -144,7 +145,8 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
 
 /* ---- self penetration: HandModel.self_penetration (E_spen), core/hand_model.py:989-1040 ------------------ */
 int gq_self_pen_forward(const gqHand* h, const float* sphere_centers /* (B,S,3) world */, int64_t batch,
-                        float* e_spen /* (B) */, float* g_centers /* (B,S,3) dE/dcentre */, void* stream);
+                        float grad_scale, float* e_spen /* (B) */,
+                        float* g_centers /* (B,S,3) grad_scale * dE/dcentre */, void* stream);
 
 /* ---- energy composition: core/energy.py:25-28,47-62 and scripts/fit.py:434-438 ---------------------------- */
 int gq_contact_terms(const float* dist_sq, const int32_t* sign, const float* onrm, const float* closest,
@@ -167,7 +169,9 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
                     const int64_t* new_idx, int64_t batch, int pose_dim, int n_contact, float step_size,
                     int stepsize_period, float decay, float mu, float switch_possibility, int clip_grad,
                     float* ema /* (B,D) in/out */, int64_t* step /* (B) in/out */, float* pose_out, int64_t* idx_out,
-                    float* step_size_out /* (B) or NULL */, float* g2_scratch /* (D) */, void* stream);
+                    float* step_size_out /* (B) or NULL */, float* g2_scratch /* (D) */,
+                    const float* energy /* (B) or NULL: also emit the per-object z-score of the accepted energies */,
+                    int64_t batch_each, float* z_out /* (B) */, void* stream);
 int gq_zscore(const float* energy, int64_t n_obj, int64_t batch_each, float* z, void* stream);
 int gq_mala_accept(const float* new_energy, const float* u_accept, const float* z, const uint8_t* reset_mask,
                    const int64_t* step, const float* pose_new, const int64_t* idx_new, const float* grad_new,

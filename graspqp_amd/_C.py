@@ -32,7 +32,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
     """name -> (restype, argtypes) for every ``gq_*`` prototype in the header."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
-    src = re.sub(r"typedef struct gqHandDesc \{.*?\} gqHandDesc;", " ", src, flags=re.S)
+    src = re.sub(r"typedef struct (\w+) \{.*?\} \1;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"(const char\*|int)\s+(gq_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
@@ -69,6 +69,13 @@ class HandDesc(ctypes.Structure):
         ("joints_lower", ctypes.c_void_p),
         ("joints_upper", ctypes.c_void_p),
     ]
+
+
+class RowEnergyDesc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("dist_sq", "sign", "obj_dir", "hand_normals", "joints_lower",
+                                                "joints_upper", "e_fc", "e_pen", "e_spen")] + [
+        ("n", ctypes.c_int32)] + [(k, ctypes.c_float) for k in ("w_dis", "w_fc", "w_pen", "w_spen", "w_joints")] + [
+        (k, ctypes.c_void_p) for k in ("e_dis", "e_joints", "total")]
 
 
 _lib = None

@@ -52,8 +52,14 @@ __device__ __forceinline__ double gq_wave_sum_d(double v) {
   return v;
 }
 // NaN-propagating min / max (torch.min / torch.max semantics)
-__device__ __forceinline__ float gq_nanmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
-__device__ __forceinline__ float gq_nanmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ float gq_nanmin(float a, float b) {  // branch-free: v_min + unordered compare + select
+  const float m = fminf(a, b);
+  return __builtin_isunordered(a, b) ? __builtin_nanf("") : m;
+}
+__device__ __forceinline__ float gq_nanmax(float a, float b) {
+  const float m = fmaxf(a, b);
+  return __builtin_isunordered(a, b) ? __builtin_nanf("") : m;
+}
 __device__ __forceinline__ float gq_wave_nanmin(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = gq_nanmin(v, __shfl_xor(v, o, GQ_WAVE));

@@ -181,6 +181,7 @@ struct GqFkBwdArgs {
   int B, n, D;
   float* node_F;     // (B, J, 6) workspace
   float* grad_pose;  // (B, D)
+  gqRowEnergyDesc en;  // en.total != nullptr: E_dis, E_joints (+ its gradient) and the weighted total ride along
 };
 
 __device__ __forceinline__ void gq_add6(float* a, gq3 f, gq3 m) {
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     __syncthreads();
   }
   float* go = g.grad_pose + (size_t)row * g.D;
+  float ej = 0.0f;
   if (lane < h.J) {  // d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
     const gq3 f = gq_mk(nf[0], nf[1], nf[2]), m = gq_mk(nf[3], nf[4], nf[5]);
     const GqT Wj = gq_t_load(W + lane * 12);
@@ -301,7 +303,36 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     const gq3 o = gq_t_pos(Wj);
     float gth = (h.node_type[lane] == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
     if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + lane];
+    if (g.en.total) {  // E_joints = sum relu(theta - hi) + relu(lo - theta)  (energy.py:47-54)
+      const float th = hp[9 + lane], hi = g.en.joints_upper[lane], lo = g.en.joints_lower[lane];
+      if (th > hi) {
+        ej += th - hi;
+        gth += g.en.w_joints;
+      }
+      if (th < lo) {
+        ej += lo - th;
+        gth -= g.en.w_joints;
+      }
+    }
     go[9 + lane] = gth;
+  }
+  if (g.en.total) {
+    float ed = 0.0f;  // E_dis = sum_i exp(1 + vC_i . nH_i) |d_i|  (energy.py:25-28)
+    for (int c = lane; c < g.en.n; c += GQ_WAVE) {
+      const size_t t = (size_t)row * g.en.n + c;
+      const float root = sqrtf(g.en.dist_sq[t] + 1e-8f);
+      const float sg = (float)g.en.sign[t];
+      const float dt = sg * (g.en.obj_dir[t * 3] * g.en.hand_normals[t * 3] + g.en.obj_dir[t * 3 + 1] * g.en.hand_normals[t * 3 + 1] +
+                             g.en.obj_dir[t * 3 + 2] * g.en.hand_normals[t * 3 + 2]);
+      ed += expf(1.0f + dt) * root;
+    }
+    const float e_dis = gq_dpp_sum(ed), e_joints = gq_dpp_sum(ej);
+    if (lane == 0) {
+      g.en.e_dis[row] = e_dis;
+      g.en.e_joints[row] = e_joints;
+      g.en.total[row] = g.en.w_dis * e_dis + g.en.w_fc * g.en.e_fc[row] + g.en.w_pen * g.en.e_pen[row] +
+                        g.en.w_spen * g.en.e_spen[row] + g.en.w_joints * e_joints;
+    }
   }
   // ---- global pose: fixed-tree sums over the lanes ---------------------------------------------------------------------
   float tot[12];
@@ -527,8 +558,15 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
 int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                    const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
                    const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
-                   const float* g_R, float* grad_pose, void* workspace, size_t workspace_bytes, void* stream) {
+                   const float* g_R, float* grad_pose, const gqRowEnergyDesc* energy, void* workspace,
+                   size_t workspace_bytes, void* stream) {
   GQ_REQUIRE(h && hand_pose && Rg && link_T && grad_pose && workspace, "fk_backward: null pointer");
+  if (energy) {
+    const gqRowEnergyDesc& e = *energy;
+    GQ_REQUIRE(e.dist_sq && e.sign && e.obj_dir && e.hand_normals && e.joints_lower && e.joints_upper && e.e_fc &&
+                   e.e_pen && e.e_spen && e.e_dis && e.e_joints && e.total && e.n >= 0,
+               "fk_backward: incomplete gqRowEnergyDesc");
+  }
   GQ_REQUIRE(batch > 0 && n_contact >= 0, "fk_backward: bad sizes");
   GQ_REQUIRE(workspace_bytes >= (size_t)batch * h->J * 18 * sizeof(float), "fk_backward: workspace too small");
   GqFkBwdArgs a{};
@@ -550,6 +588,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
   a.D = 9 + h->J;
   a.node_F = (float*)workspace + (size_t)batch * h->J * 12;
   a.grad_pose = grad_pose;
+  if (energy) a.en = *energy;
   GQ_REQUIRE(a.n + h->S <= GQ_FK_MAX_ITEMS, "fk_backward: n_contact + n_spheres = %d exceeds %d", a.n + h->S,
              GQ_FK_MAX_ITEMS);
   hipLaunchKernelGGL(gq_fk_backward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);

@@ -10,11 +10,12 @@
 // DPP row_shr/row_bcast network (common.h), no LDS.  The PDIPM control flow is the one of qp_kernels.h
 // (qpth 0.0.18 semantics, oracle/ref_cpu/qp.py::pdipm_forward_box).
 #include "qp_kernels.h"
+#include "wave.h"
 
 template <int M>
 struct GqSmall {
   static constexpr int T = M * (M + 1) / 2;
-  // in-place Cholesky of the packed lower triangle (idx(i,j) = i(i+1)/2 + j)
+  // in-place Cholesky of the packed lower triangle (idx(i,j) = i(i+1)/2 + j); the diagonal slots receive 1 / L_ii
   static __device__ __forceinline__ void factor(double (&G)[T]) {
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -23,8 +24,8 @@ struct GqSmall {
         double s = G[i * (i + 1) / 2 + j];
 #pragma unroll
         for (int t = 0; t < j; ++t) s -= G[i * (i + 1) / 2 + t] * G[j * (j + 1) / 2 + t];
-        if (i == j) G[i * (i + 1) / 2 + j] = sqrt(s);
-        else G[i * (i + 1) / 2 + j] = s / G[j * (j + 1) / 2 + j];
+        if (i == j) G[i * (i + 1) / 2 + j] = gq_rsq_d(s);
+        else G[i * (i + 1) / 2 + j] = s * G[j * (j + 1) / 2 + j];
       }
     }
   }
@@ -33,13 +34,13 @@ struct GqSmall {
     for (int i = 0; i < M; ++i) {
 #pragma unroll
       for (int t = 0; t < i; ++t) v[i] -= L[i * (i + 1) / 2 + t] * v[t];
-      v[i] /= L[i * (i + 1) / 2 + i];
+      v[i] *= L[i * (i + 1) / 2 + i];
     }
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
 #pragma unroll
       for (int t = i + 1; t < M; ++t) v[i] -= L[t * (t + 1) / 2 + i] * v[t];
-      v[i] /= L[i * (i + 1) / 2 + i];
+      v[i] *= L[i * (i + 1) / 2 + i];
     }
   }
 };
@@ -58,7 +59,7 @@ struct GqLr {
     for (int i = 0; i < T; ++i) part[i] = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      il[c] = live[c] ? 1.0 / (double)lam[c] : 0.0;
+      il[c] = live[c] ? gq_rcp_d((double)lam[c]) : 0.0;
 #pragma unroll
       for (int i = 0; i < M; ++i) {
         const double ai = (double)a[c][i] * il[c];
@@ -66,10 +67,11 @@ struct GqLr {
         for (int j = 0; j <= i; ++j) part[i * (i + 1) / 2 + j] += ai * (double)a[c][j];
       }
     }
+    gq_wave_sums_d<T>(part);
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = gq_dpp_sum_d(part[i * (i + 1) / 2 + j]) + (i == j ? 1.0 : 0.0);
+      for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = part[i * (i + 1) / 2 + j] + (i == j ? 1.0 : 0.0);
     GqSmall<M>::factor(L);
   }
   // dx = (Lam + A'A)^-1 rhs
@@ -80,8 +82,9 @@ struct GqLr {
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < NC; ++c) s += (double)a[c][i] * ((double)rhs[c] * il[c]);
-      v[i] = gq_dpp_sum_d(s);
+      v[i] = s;
     }
+    gq_wave_sums_d<M>(v);
     GqSmall<M>::solve(L, v);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {

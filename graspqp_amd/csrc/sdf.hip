@@ -523,6 +523,11 @@ struct GqPenBwdArgs {
   int B, P, L, D, batch_each;
   float* wrench;  // (B, L, 6)
   float* gRt;     // (B, 12)
+  const float* dis;  // when w == nullptr: w = w_pen * [dis > 0]  (energy.py:59-61), and e_pen[row] = sum relu(dis)
+  float w_pen;
+  float* e_pen;
+  uint64_t* span;      // optional: the forward query's 64 x {min start, max end} shards ...
+  uint64_t* span_acc;  // ... folded into {sum of spans, launches} and re-armed here (the query is over by now)
 };
 
 // One block per row, surface points in super-chunks of 4096.  Phase A: every thread reads the weights of its 16 points
@@ -540,12 +545,35 @@ __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
   const int obj = row / g.batch_each;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
+  if (g.span && row == 0 && wv == 0) {
+    unsigned long long t0 = g.span[2 * lane], t1 = g.span[2 * lane + 1];
+    if (t1 == 0ull) t0 = ~0ull;  // shard saw no block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a0 = __shfl_xor(t0, o, GQ_WAVE), a1 = __shfl_xor(t1, o, GQ_WAVE);
+      t0 = a0 < t0 ? a0 : t0;
+      t1 = a1 > t1 ? a1 : t1;
+    }
+    g.span[2 * lane] = ~0ull;
+    g.span[2 * lane + 1] = 0ull;
+    if (lane == 0 && t1 > t0) {
+      g.span_acc[0] += t1 - t0;
+      g.span_acc[1] += 1ull;
+    }
+  }
+  float e_acc = 0.0f;
   for (int base = 0; base < g.P; base += GQ_PENB_K * 256) {
     float w[GQ_PENB_K];
 #pragma unroll
     for (int k = 0; k < GQ_PENB_K; ++k) {
       const int pt = base + k * 256 + tid;
-      w[k] = (pt < g.P) ? g.w[(size_t)row * g.P + pt] : 0.0f;
+      if (g.w) {
+        w[k] = (pt < g.P) ? g.w[(size_t)row * g.P + pt] : 0.0f;
+      } else {
+        const float d = (pt < g.P) ? g.dis[(size_t)row * g.P + pt] : 0.0f;
+        w[k] = d > 0.0f ? g.w_pen : 0.0f;
+        e_acc += d > 0.0f ? d : 0.0f;
+      }
     }
     unsigned long long m[GQ_PENB_K];
 #pragma unroll
@@ -630,6 +658,12 @@ __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
       }
     }
     __syncthreads();
+  }
+  if (g.e_pen) {  // fixed order: thread-local (k ascending), DPP tree per wave, waves 0..3
+    const float ws = gq_dpp_sum(e_acc);
+    if (lane == 0) s_rec[wv] = ws;
+    __syncthreads();
+    if (tid == 0) g.e_pen[row] = ((s_rec[0] + s_rec[1]) + s_rec[2]) + s_rec[3];
   }
 }
 
@@ -1022,9 +1056,10 @@ int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, s
 int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                          const float* grad_dis, const int32_t* link, const float* gvec, float* link_wrench, float* gRt,
-                         void* stream) {
-  GQ_REQUIRE(surface_points && hand_pose && Rg && grad_dis && link && gvec && link_wrench && gRt,
-             "hand_pen_backward: null");
+                         const float* dis, float w_pen, float* e_pen, uint64_t* span, uint64_t* span_acc, void* stream) {
+  GQ_REQUIRE(surface_points && hand_pose && Rg && link && gvec && link_wrench && gRt, "hand_pen_backward: null");
+  GQ_REQUIRE(grad_dis || (dis && e_pen), "hand_pen_backward: need grad_dis, or dis + e_pen for the fused E_pen form");
+  GQ_REQUIRE(!span || span_acc, "hand_pen_backward: span without span_acc");
   GQ_REQUIRE(n_links > 0 && n_links <= 160 && n_obj > 0 && n_surface > 0 && batch_each > 0, "hand_pen_backward: sizes");
   GqPenBwdArgs a{};
   a.surf = surface_points;
@@ -1040,6 +1075,11 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
   a.batch_each = (int)batch_each;
   a.wrench = link_wrench;
   a.gRt = gRt;
+  a.dis = dis;
+  a.w_pen = w_pen;
+  a.e_pen = grad_dis ? nullptr : e_pen;
+  a.span = span;
+  a.span_acc = span_acc;
   hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;

@@ -382,7 +382,7 @@ def _fk_backward(hand, hp, ix, Rg, LT, ws, nb, gcp, gcn, gsc, wrench, gRt, gthet
             _C.f32(None if gcp is None else _c(gcp)), _C.f32(None if gcn is None else _c(gcn)),
             _C.f32(None if (gsc is None or hand.S == 0) else _c(gsc)), _C.f32(None if wrench is None else _c(wrench)),
             _C.f32(None if gRt is None else _c(gRt)), _C.f32(None if gtheta is None else _c(gtheta)),
-            _C.f32(None if gR is None else _c(gR)), _C.f32(gp), _C.ptr(ws), nb, _C.stream_ptr())
+            _C.f32(None if gR is None else _c(gR)), _C.f32(gp), None, _C.ptr(ws), nb, _C.stream_ptr())
     return gp
 
 
@@ -430,7 +430,8 @@ class _HandPen(torch.autograd.Function):
         wrench = torch.empty(B, hand.L, 6, device=dev)
         gRt = torch.empty(B, 12, device=dev)
         _C.call("gq_hand_pen_backward", hand.L, _C.f32(sp), n_obj, P, ctx.batch_each, _C.f32(hp), hp.shape[1], _C.f32(Rg),
-                _C.f32(_c(g)), _C.i32(link), _C.f32(gvec), _C.f32(wrench), _C.f32(gRt), _C.stream_ptr())
+                _C.f32(_c(g)), _C.i32(link), _C.f32(gvec), _C.f32(wrench), _C.f32(gRt), None, 0.0, None, None, None,
+                _C.stream_ptr())
         gp = _fk_backward(hand, hp, idx, Rg, LT, ws, ctx.nb, None, None, None, wrench, gRt, None, None)
         return gp, None, None, None, None, None, None, None, None, None
 

@@ -4,8 +4,8 @@ No autograd, no host synchronisation, no allocation inside ``step``: all buffers
 whole iteration is capturable into a hipGraph (``capture()``).  It runs exactly the kernels that the autograd
 route (``graspqp_amd.core``) runs, in the reference's order:
 
-    propose -> FK+contacts -> object SDF -> contact terms (E_dis grads) -> E_fc fwd -> hand penetration ->
-    self penetration -> row energies (+total) -> E_fc bwd -> penetration bwd -> FK bwd -> z-score -> accept
+    propose (+z-score) -> FK+contacts -> { object SDF -> contact terms -> E_fc fwd -> E_fc bwd | hand penetration
+    fwd -> bwd (+E_pen) | self penetration } -> FK bwd (+E_dis, E_joints, total) -> accept
 
 State (device tensors): hand_pose (B,D), contact_idx (B,n) i64, grad (B,D), energy (B), ema (B,D), step (B) i64,
 terms (5,B) = accepted [E_dis, E_fc, E_pen, E_spen, E_joints].
@@ -91,16 +91,34 @@ class GraspStepper:
         self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)  # queue counters start at zero
         self._graph = None
         self.kernel_events = None
-        self._span = None
+        self._span = torch.zeros(64, 2, dtype=torch.int64, device=self.dev)
+        self._span[:, 0] = -1  # {~0, 0}: armed
+        self._span_acc = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self._side = None
         self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
+        e = _C.RowEnergyDesc()
+        e.dist_sq, e.sign, e.obj_dir, e.hand_normals = (t.data_ptr() for t in (self.d2, self.sgn, self.onrm, self.cnrm))
+        e.joints_lower, e.joints_upper = self.jlo.data_ptr(), self.jhi.data_ptr()
+        e.e_fc, e.e_pen, e.e_spen = (self.terms_new[i].data_ptr() for i in (1, 2, 3))
+        e.n = n
+        e.w_dis, e.w_fc, e.w_pen, e.w_spen, e.w_joints = (float(self.w[k]) for k in TERM_NAMES)
+        e.e_dis, e.e_joints, e.total = self.terms_new[0].data_ptr(), self.terms_new[4].data_ptr(), self.total_new.data_ptr()
+        self._row_energy = e
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
-    def _eval_pre(self, pose, idx, st):
-        B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
-        C, f32, i32, i64 = _C.call, _C.f32, _C.i32, _C.i64
+    # Four pieces: FK, then three independent branches (contacts -> object SDF -> E_fc fwd+bwd | hand penetration
+    # fwd+bwd | self penetration), then FK backward with the row energies.  ``_evaluate`` runs the branches on three
+    # streams when ``fork`` is set (inside a hipGraph capture they become parallel graph branches).
+    def _eval_fk(self, pose, idx, st):
+        B, n = self.B, self.n
+        _C.call("gq_fk_forward", self.hand.handle, _C.f32(pose), _C.i64(idx), B, n, _C.f32(self.Rg), _C.f32(self.link_T),
+                _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None, _C.ptr(self.fk_ws),
+                self.fk_nb, st)
+
+    def _eval_contacts(self, st):
+        B, n, w, fc = self.B, self.n, self.w, self.fc
+        C, f32, i32 = _C.call, _C.f32, _C.i32
         e_fc = self.terms_new[1]
-        C("gq_fk_forward", self.hand.handle, f32(pose), i64(idx), B, n, f32(self.Rg), f32(self.link_T), f32(self.cpts),
-          f32(self.cnrm), f32(self.spheres) if self.S > 0 else None, _C.ptr(self.fk_ws), self.fk_nb, st)
         C("gq_sdf_forward_meshset", self.objs.handle, f32(self.cpts), B * n, self.be * n, f32(self.d2), i32(self.sgn),
           f32(self.onrm), f32(self.closest), st)
         C("gq_contact_terms", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.closest), f32(self.cpts),
@@ -109,43 +127,58 @@ class GraspStepper:
           float(fc["friction"]), float(fc["torque_weight"]), float(fc["max_limit"]), float(fc["svd_gain"]),
           float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
           _C.ptr(self.fc_ws), self.fc_nb, st)
-
-    def _eval_pen(self, pose, st, timer=None, span=None):
-        """The dominant kernel, kept as a launch of its own so bench.py can time it live: ``timer`` = HIP event pair
-        (hipExtLaunchKernelGGL start/stop events), ``span`` = device pointer to {min block start, max block end} in
-        100 MHz s_memrealtime ticks (the kernel's own execution span, what rocprofv3 reports)."""
-        _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
-                _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
-                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
-                _C.ptr(self.pen_ws) if self.penetration_only == 1 else None, self.pen_nb, timer, span, st)
-
-    def _eval_post(self, pose, idx, st):
-        B, n, P, w, fc = self.B, self.n, self.P, self.w, self.fc
-        C, f32, i32, i64 = _C.call, _C.f32, _C.i32, _C.i64
-        e_dis, e_fc, e_pen, e_spen, e_joints = (self.terms_new[i] for i in range(5))
-        if self.S > 0:
-            C("gq_self_pen_forward", self.hand.handle, f32(self.spheres), B, float(w["E_spen"]), f32(e_spen),
-              f32(self.g_sph_w), st)
-        else:
-            C("gq_fill", f32(e_spen), 0.0, B, st)
-        C("gq_row_energy", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.cnrm), f32(pose), f32(self.jlo),
-          f32(self.jhi), f32(e_fc), f32(self.pen_dis), f32(e_spen), B, n, self.J, P, float(w["E_dis"]), float(w["E_fc"]),
-          float(w["E_pen"]), float(w["E_spen"]), float(w["E_joints"]), f32(e_dis), f32(e_joints), f32(e_pen),
-          f32(self.total_new), f32(self.g_theta), f32(self.g_pen), st)
-        # backward
         C("gq_fc_backward", f32(self.cpts), f32(self.obj_normal), f32(self.cog), f32(self.w_fc_vec), B, n,
           int(fc["n_cone_vecs"]), float(fc["friction"]), float(fc["torque_weight"]), float(fc["svd_gain"]),
           float(fc["values_gain"]), 1, f32(self.g_cpts), _C.ptr(self.fc_ws), self.fc_nb, st)
-        C("gq_hand_pen_backward", self.L, f32(self.surf), self.n_obj, P, self.be, f32(pose), self.D, f32(self.Rg),
-          f32(self.g_pen), i32(self.pen_link), f32(self.pen_gvec), f32(self.wrench), f32(self.gRt), st)
-        C("gq_fk_backward", self.hand.handle, f32(pose), i64(idx), B, n, f32(self.Rg), f32(self.link_T), f32(self.g_cpts),
-          f32(self.g_cnrm), f32(self.g_sph_w) if self.S > 0 else None, f32(self.wrench), f32(self.gRt), f32(self.g_theta),
-          None, f32(self.grad_new), _C.ptr(self.fk_ws), self.fk_nb, st)
 
-    def _evaluate(self, pose, idx, st):
-        self._eval_pre(pose, idx, st)
-        self._eval_pen(pose, st)
-        self._eval_post(pose, idx, st)
+    def _eval_pen(self, pose, st, timer=None):
+        """Hand-penetration query (the roofline kernel of bench.py) + its backward.  ``timer`` = HIP event pair around
+        the query (hipExtLaunchKernelGGL start/stop events).  The query also records its own execution span in
+        100 MHz s_memrealtime ticks (64 shards of {min block start, max block end}); the backward launch folds them
+        into ``_span_acc`` = {sum, launches}, which works inside a hipGraph replay too."""
+        fused = self.penetration_only == 1
+        _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
+                _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
+                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
+                _C.ptr(self.pen_ws) if fused else None, self.pen_nb, timer, _C.ptr(self._span), st)
+        _C.call("gq_hand_pen_backward", self.L, _C.f32(self.surf), self.n_obj, self.P, self.be, _C.f32(pose), self.D,
+                _C.f32(self.Rg), None, _C.i32(self.pen_link), _C.f32(self.pen_gvec), _C.f32(self.wrench), _C.f32(self.gRt),
+                _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),
+                _C.ptr(self._span_acc), st)
+
+    def _eval_spen(self, st):
+        e_spen = self.terms_new[3]
+        if self.S > 0:
+            _C.call("gq_self_pen_forward", self.hand.handle, _C.f32(self.spheres), self.B, float(self.w["E_spen"]),
+                    _C.f32(e_spen), _C.f32(self.g_sph_w), st)
+        else:
+            _C.call("gq_fill", _C.f32(e_spen), 0.0, self.B, st)
+
+    def _eval_tail(self, pose, idx, st):
+        B, n = self.B, self.n
+        f32 = _C.f32
+        _C.call("gq_fk_backward", self.hand.handle, f32(pose), _C.i64(idx), B, n, f32(self.Rg), f32(self.link_T),
+                f32(self.g_cpts), f32(self.g_cnrm), f32(self.g_sph_w) if self.S > 0 else None, f32(self.wrench),
+                f32(self.gRt), None, None, f32(self.grad_new), ctypes.byref(self._row_energy), _C.ptr(self.fk_ws),
+                self.fk_nb, st)
+
+    def _evaluate(self, pose, idx, st, fork=False, timer=None):
+        self._eval_fk(pose, idx, st)
+        if not fork:
+            self._eval_contacts(st)
+            self._eval_pen(pose, st, timer)
+            self._eval_spen(st)
+        else:
+            main = torch.cuda.current_stream()
+            sb, sc = self._side
+            sb.wait_stream(main)
+            sc.wait_stream(main)
+            self._eval_contacts(st)
+            self._eval_pen(pose, ctypes.c_void_p(sb.cuda_stream), timer)
+            self._eval_spen(ctypes.c_void_p(sc.cuda_stream))
+            main.wait_stream(sb)
+            main.wait_stream(sc)
+        self._eval_tail(pose, idx, st)
 
     def evaluate(self, pose, idx):
         """Energy terms, total and d total / d pose at an arbitrary (pose, idx); returns clones."""
@@ -197,49 +230,26 @@ class GraspStepper:
           f32(self.hand_pose), i64(self.contact_idx), f32(self.grad), _C.u8(self.accept), f32(self.temperature), 5,
           f32(self.terms_new), f32(self.terms), st)
 
-    def _step_head(self, st):
-        self._eval_pre(self.pose_new, self.idx_new, st)
-
-    def _step_tail(self, st):
-        self._eval_post(self.pose_new, self.idx_new, st)
-
-    def _pen_timed(self, st):
-        ev = self.kernel_events
-        if ev is None:
-            self._eval_pen(self.pose_new, st)
-            return
-        i = len(ev)
-        if i >= self._span.shape[0]:
-            self._eval_pen(self.pose_new, st)
-            return
-        t = ctypes.c_void_p(0)
-        _C.call("gq_timer_create", ctypes.byref(t))
-        self._eval_pen(self.pose_new, st, t, ctypes.c_void_p(self._span[i].data_ptr()))
-        ev.append(t)
-
-    def start_kernel_timing(self, max_launches=4096):
-        """Time every hand-penetration launch from now on (bench.py)."""
-        self._span = torch.zeros(max_launches, 64, 2, dtype=torch.int64, device=self.dev)
-        self._span[:, :, 0] = -1  # 0xffff... as unsigned: atomicMin target (64 shards per launch)
+    def start_kernel_timing(self):
+        """Time the hand-penetration query from now on (bench.py): clears the in-kernel span accumulator; outside a
+        hipGraph every launch additionally gets a HIP event pair."""
+        self._span_acc.zero_()
         self.kernel_events = []
 
     def kernel_times_ms(self):
-        """-> (event_ms, span_ms): per-launch durations from the HIP event pairs and from the in-kernel
-        s_memrealtime span (100 MHz) of the launches timed since ``start_kernel_timing``."""
+        """-> (event_ms list, span_ms mean, launches): HIP-event durations of the eagerly launched queries and the mean
+        in-kernel s_memrealtime span (100 MHz) of all queries since ``start_kernel_timing``."""
         ev_ms = []
         for t in self.kernel_events or []:
             ms = ctypes.c_float(0)
             _C.call("gq_timer_elapsed_ms", t, ctypes.byref(ms))
             _C.call("gq_timer_destroy", t)
             ev_ms.append(float(ms.value))
-        n = len(ev_ms)
-        sp = self._span[:n].cpu()
-        used = sp[:, :, 1] > 0  # shards that saw a block
-        start = torch.where(used, sp[:, :, 0], torch.full_like(sp[:, :, 0], 2**62)).min(dim=1).values
-        end = sp[:, :, 1].max(dim=1).values
-        span_ms = ((end - start).double() / 1e5).tolist()  # ticks of 10 ns -> ms
+        acc = self._span_acc.cpu()
+        n = int(acc[1])
+        span_ms = (float(acc[0]) / max(n, 1)) / 1e5  # ticks of 10 ns -> ms
         self.kernel_events = None
-        return ev_ms, span_ms
+        return ev_ms, span_ms, n
 
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""
@@ -253,43 +263,44 @@ class GraspStepper:
         st = _C.stream_ptr()
         self._propose(st)
         if self._graph is not None:
-            self._graph[0].replay()
-            self._pen_timed(st)
-            self._graph[1].replay()
+            self._graph.replay()
         else:
-            self._step_head(st)
-            self._pen_timed(st)
-            self._step_tail(st)
+            timer = None
+            if self.kernel_events is not None and len(self.kernel_events) < 4096:
+                timer = ctypes.c_void_p(0)
+                _C.call("gq_timer_create", ctypes.byref(timer))
+                self.kernel_events.append(timer)
+            self._evaluate(self.pose_new, self.idx_new, st, timer=timer)
         self._accept(st)
 
-    def capture(self):
-        """Capture the energy + gradient evaluation of one iteration into two hipGraphs (the launches before / after the
-        hand-penetration query).  Propose, the penetration query and accept stay ordinary launches: the first and last
-        read the current slice of the pre-generated random numbers, the middle one is timed by bench.py.  The state is
-        saved and restored around the warm-up + capture passes, so capturing does not advance the chain."""
+    def capture(self, fork=True):
+        """Capture the energy + gradient evaluation of one iteration into a hipGraph whose three independent branches
+        (contacts/object SDF/E_fc | hand penetration | self penetration) may run concurrently.  Propose and accept stay
+        ordinary launches: they read the current slice of the pre-generated random numbers.  The state is saved and
+        restored around the warm-up + capture passes, so capturing does not advance the chain."""
         saved = [t.clone() for t in (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema,
-                                     self.step_count, self.terms)]
+                                     self.step_count, self.terms, self._span_acc)]
+        rng = (self.gen.get_state(), self._draw_pos)
+        if self._side is None:
+            self._side = (torch.cuda.Stream(), torch.cuda.Stream())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         self.draw()
         with torch.cuda.stream(s):
             st = _C.stream_ptr()
             self._propose(st)
-            self._step_head(st)
-            self._eval_pen(self.pose_new, st)
-            self._step_tail(st)
+            self._evaluate(self.pose_new, self.idx_new, st, fork=fork)
             self._accept(st)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g0, g1 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0):
-            self._step_head(_C.stream_ptr())
-        self._eval_pen(self.pose_new, _C.stream_ptr())
-        with torch.cuda.graph(g1):
-            self._step_tail(_C.stream_ptr())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._evaluate(self.pose_new, self.idx_new, _C.stream_ptr(), fork=fork)
         torch.cuda.synchronize()
         for t, v in zip((self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema, self.step_count,
-                         self.terms), saved):
+                         self.terms, self._span_acc), saved):
             t.copy_(v)
-        self._graph = (g0, g1)
-        return self._graph
+        self.gen.set_state(rng[0])
+        self._draw_pos = rng[1]
+        self._graph = g
+        return g

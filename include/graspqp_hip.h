@@ -115,14 +115,32 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
                   int n_contact, float* Rg /* (B,9) */, float* link_T /* (B,L,12) */, float* contact_points /* (B,n,3) */,
                   float* contact_normals /* (B,n,3) */, float* sphere_centers /* (B,S,3) or NULL */, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* Optional tail of gq_fk_backward: E_dis, E_joints (with its gradient) and the weighted total of one row
+ * (core/energy.py:25-28,47-54; scripts/fit.py:434-438), so the iteration needs no separate reduction launch.     */
+typedef struct gqRowEnergyDesc {
+  const float* dist_sq;      /* (B,n) object SDF of the contact points (gq_sdf_forward*)  */
+  const int32_t* sign;       /* (B,n)                                                      */
+  const float* obj_dir;      /* (B,n,3) unit (p - closest)/|.|                             */
+  const float* hand_normals; /* (B,n,3) world contact normals of the hand (gq_fk_forward)  */
+  const float* joints_lower; /* (J) */
+  const float* joints_upper; /* (J) */
+  const float* e_fc;         /* (B) */
+  const float* e_pen;        /* (B) */
+  const float* e_spen;       /* (B) */
+  int32_t n;                 /* contacts per row */
+  float w_dis, w_fc, w_pen, w_spen, w_joints;
+  float* e_dis;              /* (B) out */
+  float* e_joints;           /* (B) out */
+  float* total;              /* (B) out: sum_k w_k E_k */
+} gqRowEnergyDesc;
 /* analytic backward (replaces autograd through pytorch_kinematics); the workspace must be the one written by
  * gq_fk_forward for the same hand_pose.  Any gradient input may be NULL.  g_link_wrench (B,L,6) = (f, m about the
- * hand origin) in the hand frame and g_Rt (B,12) come from gq_hand_pen_backward.                             */
+ * hand origin) in the hand frame and g_Rt (B,12) come from gq_hand_pen_backward.  energy: NULL or see above.    */
 int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                    const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
                    const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
-                   const float* g_R, float* grad_pose /* (B,9+J) */, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   const float* g_R, float* grad_pose /* (B,9+J) */, const gqRowEnergyDesc* energy, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
  * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.
@@ -138,10 +156,15 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (
                         void* stream);
 int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes);
 int gq_debug_set_pen_counters(uint64_t* counters /* device, 4 words, or NULL */);
+/* grad_dis (B,P) = upstream d E / d dis.  grad_dis == NULL selects the fused E_pen form: the weights are
+ * w_pen * [dis > 0] and e_pen (B) = sum_j relu(dis_j) is written as well (core/energy.py:59-61).
+ * span / span_acc (optional): the 64 x {min start, max end} shards filled by gq_hand_pen_forward are folded into
+ * span_acc = {sum of launch spans, launches} (100 MHz ticks) and re-armed, so a hipGraph replay can time the query. */
 int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
-                         const float* grad_dis /* (B,P) */, const int32_t* link, const float* gvec,
-                         float* link_wrench /* (B,L,6) */, float* gRt /* (B,12) */, void* stream);
+                         const float* grad_dis /* (B,P) or NULL */, const int32_t* link, const float* gvec,
+                         float* link_wrench /* (B,L,6) */, float* gRt /* (B,12) */, const float* dis /* (B,P) */,
+                         float w_pen, float* e_pen /* (B) */, uint64_t* span, uint64_t* span_acc, void* stream);
 
 /* ---- self penetration: HandModel.self_penetration (E_spen), core/hand_model.py:989-1040 ------------------ */
 int gq_self_pen_forward(const gqHand* h, const float* sphere_centers /* (B,S,3) world */, int64_t batch,

@@ -451,14 +451,17 @@ def test_config2_properties_and_determinism(gq):
     hp = _rand_pose(spec, B, 21, spread=0.14).float().cuda()
     idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(1)).cuda()
     outs = []
-    for rep in range(2):
+    for rep in range(3):
         st = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n, seed=7)
         st.reset(hp, idx)
+        if rep == 2:
+            st.capture()  # hipGraph with the three branches in parallel: same kernels, same results
         for _ in range(3):
             st.step()
         torch.cuda.synchronize()
         outs.append((st.energy.clone(), st.hand_pose.clone(), st.grad.clone(), st.terms.clone()))
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "iteration must be bitwise reproducible"
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[2])), "hipGraph replay must equal the eager launches"
     e, pose, grad, terms = outs[0]
     assert torch.isfinite(e).all() and torch.isfinite(grad).all()
     assert (terms[2] >= 0).all() and (terms[3] >= 0).all() and (terms[4] >= 0).all() and (terms[0] >= 0).all()

@@ -31,15 +31,27 @@ struct GqWaveArgs {
   int64_t N;
   const GqFace* rec;
   const int32_t* off;      // (n_mesh+1) or null (single soup of single_F faces, no clusters)
-  const float* cl_aabb;    // (n_cl64, 8) or null
+  const float* cl_aabb;    // (n_cl64, 16) oriented cluster boxes (gq_cluster_bound) or null
   const int32_t* cl_off;   // (n_mesh+1) first 64-cluster of each mesh
   int single_F;
   int64_t queries_per_mesh;
+  unsigned long long* dbg;  // diagnostics (gq_debug_set_pen_counters): [0] += cluster visits, [1] += queries
   float* dist_sq;
   int32_t* sign;
   float* normal;
   float* closest;
 };
+
+// lower bound of the squared distance from p to any face of a cluster (oriented box of gq_cluster_bound)
+__device__ __forceinline__ float gq_cluster_lb(const float* __restrict__ r, gq3 p) {
+  const float4 c = *reinterpret_cast<const float4*>(r), u = *reinterpret_cast<const float4*>(r + 4),
+               v = *reinterpret_cast<const float4*>(r + 8), n = *reinterpret_cast<const float4*>(r + 12);
+  const gq3 d = gq_mk(p.x - c.x, p.y - c.y, p.z - c.z);
+  const float eu = fmaxf(fabsf(fmaf(d.x, u.x, fmaf(d.y, u.y, d.z * u.z))) - c.w, 0.0f);
+  const float ev = fmaxf(fabsf(fmaf(d.x, v.x, fmaf(d.y, v.y, d.z * v.z))) - u.w, 0.0f);
+  const float en = fmaxf(fabsf(fmaf(d.x, n.x, fmaf(d.y, n.y, d.z * n.z))) - v.w, 0.0f);
+  return fmaf(eu, eu, fmaf(ev, ev, en * en));
+}
 
 __device__ __forceinline__ void gq_wave_eval_cluster(const GqFace* __restrict__ rec, int f, int f1, gq3 p, float& best,
                                                      unsigned& borig, int& bi) {
@@ -70,34 +82,79 @@ __global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
     for (int f = f0 + lane; f < f1; f += GQ_WAVE) gq_wave_eval_cluster(g.rec, f, f1, p, best, borig, bi);
   } else {
     const int c0 = g.cl_off[mesh], nC = g.cl_off[mesh + 1] - c0;
-    // nearest cluster box first
-    float lbmin = GQ_INF_F;
-    int cmin = 0;
-    for (int c = lane; c < nC; c += GQ_WAVE) {
-      const float lb = gq_aabb_dist2(g.cl_aabb + (size_t)(c0 + c) * 8, p);
-      if (lb < lbmin) {
-        lbmin = lb;
-        cmin = c;
+    // Best-first over the 64-face clusters: lane l keeps the lower bounds of clusters cb + l, cb + 64 + l, ... in
+    // registers.  Each round takes the (up to) GQ_TOPK unvisited clusters with the smallest bounds that can still beat
+    // the best distance found, loads their faces together (one face per lane and cluster -- the GQ_TOPK record loads
+    // are in flight at once, which is what matters: a round is one L2 round trip) and evaluates them.  It stops as
+    // soon as the smallest remaining bound exceeds the best distance: for a point at distance d only clusters whose
+    // box intersects the ball of radius d are ever touched.
+    constexpr int KC = 4;  // 256 clusters (16384 faces) per pass
+    constexpr int GQ_TOPK = 4;
+    float ub = GQ_INF_F;
+    int visits = 0;
+    for (int cb = 0; cb < nC; cb += KC * GQ_WAVE) {
+      float lb[KC];
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        const int c = cb + k * GQ_WAVE + lane;
+        lb[k] = (c < nC) ? gq_cluster_lb(g.cl_aabb + (size_t)(c0 + c) * 16, p) * 0.9999f : GQ_INF_F;
       }
-    }
-    {
-      const float lbw = gq_dpp_min(lbmin);
-      const unsigned long long who = __ballot(lbmin == lbw);
-      cmin = gq_readlane_i(cmin, who ? __ffsll((long long)who) - 1 : 0);
-    }
-    gq_wave_eval_cluster(g.rec, f0 + cmin * 64 + lane, f1, p, best, borig, bi);
-    float ub = gq_dpp_min(best);
-    for (int cb = 0; cb < nC; cb += GQ_WAVE) {
-      const int c = cb + lane;
-      const float lb = (c < nC && c != cmin) ? gq_aabb_dist2(g.cl_aabb + (size_t)(c0 + c) * 8, p) : GQ_INF_F;
-      unsigned long long mask = __ballot(lb * 0.9999f <= ub);
-      while (mask) {
-        const int s = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        if (gq_readlane(lb, s) * 0.9999f > ub) continue;  // ub may have shrunk meanwhile
-        gq_wave_eval_cluster(g.rec, f0 + (cb + s) * 64 + lane, f1, p, best, borig, bi);
+      for (;;) {
+        int pick[GQ_TOPK];
+#pragma unroll
+        for (int j = 0; j < GQ_TOPK; ++j) {
+          float m = lb[0];
+          int mk = 0;
+#pragma unroll
+          for (int k = 1; k < KC; ++k) {
+            if (lb[k] < m) {
+              m = lb[k];
+              mk = k;
+            }
+          }
+          const float mw = gq_dpp_min(m);
+          pick[j] = -1;
+          if (mw <= ub) {  // wave-uniform; false when everything is visited (inf) or NaN
+            const unsigned long long who = __ballot(m == mw);
+            const int src = __ffsll((long long)who) - 1;
+            pick[j] = cb + gq_readlane_i(mk, src) * GQ_WAVE + src;
+            if (lane == src) {
+#pragma unroll
+              for (int k = 0; k < KC; ++k)
+                if (k == mk) lb[k] = GQ_INF_F;
+            }
+          }
+        }
+        if (pick[0] < 0) break;
+        GqFace fc[GQ_TOPK];
+#pragma unroll
+        for (int j = 0; j < GQ_TOPK; ++j) {
+          const int f = f0 + pick[j] * 64 + lane;
+          if (pick[j] >= 0 && f < f1) fc[j] = g.rec[f];
+        }
+#pragma unroll
+        for (int j = 0; j < GQ_TOPK; ++j) {
+          const int f = f0 + pick[j] * 64 + lane;
+          if (pick[j] >= 0 && f < f1) {
+            const gq3 d = p - gq_mk(fc[j].r0.x, fc[j].r0.y, fc[j].r0.z);
+            const float d2 = gq_tri_rank(fc[j], d);
+            const unsigned orig = (unsigned)__float_as_int(fc[j].r5.z);
+            if (d2 < best || (d2 == best && orig < borig)) {
+              best = d2;
+              borig = orig;
+              bi = f;
+            }
+          }
+          visits += pick[j] >= 0;
+        }
         ub = gq_dpp_min(best);
       }
+    }
+    if (g.dbg && lane == 0) {
+      atomicAdd(&g.dbg[0], (unsigned long long)visits);
+      atomicAdd(&g.dbg[1], 1ull);
+      atomicMax(&g.dbg[2], (unsigned long long)visits);
+      if (visits > 16) atomicAdd(&g.dbg[3], 1ull);
     }
   }
   // winner = smallest distance, then smallest original face index (two DPP min passes)
@@ -728,7 +785,7 @@ struct gqMeshSet {
   float* aabb_dev;     // (n_mesh, 8) box of each mesh in its own frame
   float* sub_aabb_dev; // (n_sub, 8) boxes of 16-face sub-clusters
   int32_t* sub_off_dev;   // (n_mesh+1)
-  float* cl_aabb_dev;  // (n_cl, 8) boxes of 64-face clusters
+  float* cl_aabb_dev;  // (n_cl, 16) oriented boxes of the 64-face clusters (gq_cluster_bound)
   int32_t* cl_off_dev;    // (n_mesh+1)
   uint32_t* occ_dev;   // (n_mesh, 1024) occupancy bits or null (gq_meshset_build_occupancy)
   float* occ_invz_dev; // (n_mesh)
@@ -737,6 +794,7 @@ struct gqMeshSet {
 };
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 static inline uint32_t gq_spread10(uint32_t v) {
@@ -763,6 +821,93 @@ static void gq_box_of(const float* fv, const int32_t* perm, int64_t a, int64_t b
 }
 
 static unsigned long long* gq_pen_dbg_ = nullptr;
+
+// Bound of a 64-face cluster: an oriented box, 16 floats = [centre.xyz, h_u][u.xyz, h_v][v.xyz, h_n][n.xyz, 0].
+// n = area-weighted mean normal of the patch, u = principal direction of its vertices in the plane orthogonal to n,
+// v = n x u.  A Morton patch of a surface mesh is nearly planar, so the box is ~1 mm thick along n and hugs the patch
+// laterally -- for a query point several centimetres away the neighbouring patches are only millimetres farther than
+// the nearest one, and an axis-aligned box around a tilted patch is too loose to tell them apart.
+static void gq_cluster_bound(const float* fv, const int32_t* perm, int64_t a, int64_t b, float* out16) {
+  double n[3] = {0, 0, 0}, c0[3] = {0, 0, 0};
+  for (int64_t i = a; i < b; ++i) {
+    const float* v = fv + (int64_t)perm[i] * 9;
+    const double e1[3] = {(double)v[3] - v[0], (double)v[4] - v[1], (double)v[5] - v[2]};
+    const double e2[3] = {(double)v[6] - v[0], (double)v[7] - v[1], (double)v[8] - v[2]};
+    n[0] += e1[1] * e2[2] - e1[2] * e2[1];
+    n[1] += e1[2] * e2[0] - e1[0] * e2[2];
+    n[2] += e1[0] * e2[1] - e1[1] * e2[0];
+    for (int k = 0; k < 9; ++k) c0[k % 3] += v[k];
+  }
+  const double cnt = 3.0 * (double)(b - a);
+  for (int k = 0; k < 3; ++k) c0[k] /= cnt;
+  double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  if (len > 1e-30) {
+    for (int k = 0; k < 3; ++k) n[k] /= len;
+  } else {
+    n[0] = 0; n[1] = 0; n[2] = 1;
+  }
+  // t1 orthogonal to n (drop the smallest component), t2 = n x t1
+  double t1[3], t2[3];
+  {
+    const int m = (std::fabs(n[0]) <= std::fabs(n[1]) && std::fabs(n[0]) <= std::fabs(n[2])) ? 0
+                  : (std::fabs(n[1]) <= std::fabs(n[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[m] = 1.0;
+    const double d = n[m];
+    for (int k = 0; k < 3; ++k) t1[k] = e[k] - d * n[k];
+    const double l = std::sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    for (int k = 0; k < 3; ++k) t1[k] /= l;
+    t2[0] = n[1] * t1[2] - n[2] * t1[1];
+    t2[1] = n[2] * t1[0] - n[0] * t1[2];
+    t2[2] = n[0] * t1[1] - n[1] * t1[0];
+  }
+  double cxx = 0, cxy = 0, cyy = 0;
+  for (int64_t i = a; i < b; ++i) {
+    const float* v = fv + (int64_t)perm[i] * 9;
+    for (int c = 0; c < 3; ++c) {
+      const double q[3] = {v[c * 3] - c0[0], v[c * 3 + 1] - c0[1], v[c * 3 + 2] - c0[2]};
+      const double x = q[0] * t1[0] + q[1] * t1[1] + q[2] * t1[2], y = q[0] * t2[0] + q[1] * t2[1] + q[2] * t2[2];
+      cxx += x * x;
+      cxy += x * y;
+      cyy += y * y;
+    }
+  }
+  const double th = 0.5 * std::atan2(2.0 * cxy, cxx - cyy);
+  float ax[3][3];  // u, v, n rounded to fp32 (the extents below are taken along the ROUNDED axes)
+  for (int k = 0; k < 3; ++k) {
+    ax[0][k] = (float)(std::cos(th) * t1[k] + std::sin(th) * t2[k]);
+    ax[1][k] = (float)(-std::sin(th) * t1[k] + std::cos(th) * t2[k]);
+    ax[2][k] = (float)n[k];
+  }
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, mag = 0.0;
+  for (int64_t i = a; i < b; ++i) {
+    const float* v = fv + (int64_t)perm[i] * 9;
+    for (int c = 0; c < 3; ++c) {
+      const double q[3] = {v[c * 3] - c0[0], v[c * 3 + 1] - c0[1], v[c * 3 + 2] - c0[2]};
+      for (int k = 0; k < 3; ++k) {
+        const double s = q[0] * ax[k][0] + q[1] * ax[k][1] + q[2] * ax[k][2];
+        lo[k] = s < lo[k] ? s : lo[k];
+        hi[k] = s > hi[k] ? s : hi[k];
+      }
+      const double m = std::fabs((double)v[c * 3]) + std::fabs((double)v[c * 3 + 1]) + std::fabs((double)v[c * 3 + 2]);
+      mag = m > mag ? m : mag;
+    }
+  }
+  double ctr[3] = {c0[0], c0[1], c0[2]};
+  for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < 3; ++j) ctr[j] += 0.5 * (lo[k] + hi[k]) * ax[k][j];
+  const double pad = 1e-6 * mag + 1e-12;  // fp32 evaluation on the device + rounding of the centre
+  for (int k = 0; k < 3; ++k) {
+    out16[k] = (float)ctr[k];
+    out16[4 + k] = ax[0][k];
+    out16[8 + k] = ax[1][k];
+    out16[12 + k] = ax[2][k];
+  }
+  out16[3] = (float)(0.5 * (hi[0] - lo[0]) + pad);
+  out16[7] = (float)(0.5 * (hi[1] - lo[1]) + pad);
+  out16[11] = (float)(0.5 * (hi[2] - lo[2]) + pad);
+  out16[15] = 0.0f;
+}
 
 extern "C" {
 
@@ -813,11 +958,11 @@ int gq_meshset_create(const float* face_verts_host, const int32_t* face_offset_h
       gq_box_of(face_verts_host, perm.data(), i, std::min<int64_t>(i + 16, b), &sub_bb[sub_bb.size() - 8]);
     }
     for (int64_t i = a; i < b; i += 64) {
-      cl_bb.resize(cl_bb.size() + 8);
-      gq_box_of(face_verts_host, perm.data(), i, std::min<int64_t>(i + 64, b), &cl_bb[cl_bb.size() - 8]);
+      cl_bb.resize(cl_bb.size() + 16);
+      gq_cluster_bound(face_verts_host, perm.data(), i, std::min<int64_t>(i + 64, b), &cl_bb[cl_bb.size() - 16]);
     }
     sub_off[m + 1] = (int32_t)(sub_bb.size() / 8);
-    cl_off[m + 1] = (int32_t)(cl_bb.size() / 8);
+    cl_off[m + 1] = (int32_t)(cl_bb.size() / 16);
   }
   float* tmp = nullptr;
   int32_t* perm_dev = nullptr;
@@ -962,6 +1107,7 @@ int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_p
   w.cl_aabb = ms->cl_aabb_dev;
   w.cl_off = ms->cl_off_dev;
   w.queries_per_mesh = queries_per_mesh;
+  w.dbg = gq_pen_dbg_;
   w.dist_sq = dist_sq;
   w.sign = sign;
   w.normal = normal;

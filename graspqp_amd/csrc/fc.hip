@@ -3,7 +3,7 @@
 //   E_fc = 2 (1/2 |F x|^2 + 0.01) exp(-gain (prod sigma_i(F))^(1/6))  (span.py:402, registry.py:82-87),
 // and its gradient with respect to the contact points (contact normals come from the object SDF and are
 // constants for autograd, object_model.py:246).
-#include "common.h"
+#include "fc_dev.h"
 
 int gq_lsq_boxqp_iterate_(const float* A, float lower_s, float upper_s, int64_t batch, int m, int nz, float ridge,
                           float eps, int max_iter, int32_t* n_iter, void* workspace, size_t workspace_bytes,
@@ -12,39 +12,6 @@ int gq_lsq_boxqp_backward_scaled_(const float* A, const float* lam, const float*
                                   int64_t batch, int m, int nz, float ridge, float* dx, float* dlam,
                                   const float* scale_ge, const float* scale_svd, float svd_gain, float values_gain,
                                   void* stream);
-
-struct GqCone {
-  gq3 f;    // cone edge (already divided by k)
-  gq3 tau;  // torque_weight * (r x f)
-  gq3 r;
-};
-
-// column i = contact c = i / k, edge e = i % k
-__device__ __forceinline__ GqCone gq_cone_column(const float* cp, const float* cn, const float* cog, int c, int e, int k,
-                                                 float mu, float tw) {
-  const gq3 n = gq_mk(cn[c * 3], cn[c * 3 + 1], cn[c * 3 + 2]);
-  const gq3 p = gq_mk(cp[c * 3], cp[c * 3 + 1], cp[c * 3 + 2]);
-  const float is3 = 0.57735026918962576f;
-  gq3 b1 = gq_mk(is3, is3, is3);
-  const float dot = (b1.x * n.x + b1.y * n.y + b1.z * n.z) * 1.0f / (sqrtf(gq_dot(n, n)) + 1e-6f);
-  if (dot > 0.9f) b1.y -= 2.0f;
-  const gq3 t1 = gq_cross(n, b1);
-  const gq3 t2 = gq_cross(n, t1);
-  const float cc = sqrtf(1.0f - mu * mu);
-  gq3 dir;
-  if (k == 4) {
-    const float s = (e < 2) ? mu : -mu;
-    dir = (e & 1) ? (s * t2) : (s * t1);
-  } else {
-    const float ang = 6.283185307179586f / (float)k * (float)e;
-    dir = mu * (cosf(ang) * t1 + sinf(ang) * t2);
-  }
-  GqCone o;
-  o.f = (1.0f / (float)k) * (dir + cc * n);
-  o.r = p - gq_mk(cog[0], cog[1], cog[2]);
-  o.tau = tw * gq_cross(o.r, o.f);
-  return o;
-}
 
 __global__ void gq_grasp_matrix_kernel(const float* __restrict__ cpts, const float* __restrict__ cnrm,
                                        const float* __restrict__ cog, int B, int n, int k, float mu, float tw,
@@ -62,31 +29,6 @@ __global__ void gq_grasp_matrix_kernel(const float* __restrict__ cpts, const flo
   o[3 * nz] = c.tau.x;
   o[4 * nz] = c.tau.y;
   o[5 * nz] = c.tau.z;
-}
-
-// 6x6 SPD Cholesky in double (every lane redundantly); returns false if not positive definite
-__device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21]) {
-  // packed lower triangle: idx(i,j) = i(i+1)/2 + j
-  bool ok = true;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      double s = G[i * (i + 1) / 2 + j];
-#pragma unroll
-      for (int t = 0; t < j; ++t) s -= Lm[i * (i + 1) / 2 + t] * Lm[j * (j + 1) / 2 + t];
-      if (i == j) {
-        if (!(s > 0.0)) {
-          ok = false;
-          s = 1.0;
-        }
-        Lm[i * (i + 1) / 2 + j] = sqrt(s);
-      } else {
-        Lm[i * (i + 1) / 2 + j] = s / Lm[j * (j + 1) / 2 + j];
-      }
-    }
-  }
-  return ok;
 }
 
 struct GqFcArgs {
@@ -293,7 +235,6 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
   }
 }
 
-static size_t gq_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" {
 
@@ -306,30 +247,6 @@ int gq_fc_workspace_bytes(int64_t batch, int n_contact, int n_cone, int max_iter
   if (rc) return rc;
   *bytes = gq_al(B * 6 * nz * 4) + gq_al(B * nz * 4) * 4 + gq_al(B * 2 * nz * 4) * 3 + gq_al(B * 4) * 2 + qp + 512;
   return GQ_OK;
-}
-
-struct GqFcWs {
-  float *F, *x, *lam, *slack, *Ftr, *dldx, *dx, *dlam, *val, *svd;
-  void* qp;
-  size_t qp_bytes;
-};
-static GqFcWs gq_fc_carve(void* base, size_t B, size_t nz, size_t total) {
-  GqFcWs w;
-  char* c = (char*)base;
-  size_t o = 0;
-  w.F = (float*)(c + o); o += gq_al(B * 6 * nz * 4);
-  w.x = (float*)(c + o); o += gq_al(B * nz * 4);
-  w.Ftr = (float*)(c + o); o += gq_al(B * nz * 4);
-  w.dldx = (float*)(c + o); o += gq_al(B * nz * 4);
-  w.dx = (float*)(c + o); o += gq_al(B * nz * 4);
-  w.lam = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
-  w.slack = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
-  w.dlam = (float*)(c + o); o += gq_al(B * 2 * nz * 4);
-  w.val = (float*)(c + o); o += gq_al(B * 4);
-  w.svd = (float*)(c + o); o += gq_al(B * 4);
-  w.qp = (void*)(c + o);
-  w.qp_bytes = total > o ? total - o : 0;
-  return w;
 }
 
 // E_fc forward (energy_fnc of reference energy.py:35-42 for energy_type "graspqp").

@@ -6,7 +6,7 @@
 //   gq_mala_accept      Metropolis accept with z-score-scaled temperature and state merge (optimizer.py:289-340,
 //                       fit.py:454-458)
 // Random numbers are inputs (drawn by the host-side generator), exactly like the oracle.
-#include "common.h"
+#include "fc_dev.h"
 
 struct GqCombineArgs {
   const float* dist_sq;   // (B,n) object SDF squared distance of the contact points
@@ -38,27 +38,20 @@ struct GqCombineArgs {
 __global__ void gq_contact_terms_kernel(GqCombineArgs g) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)g.B * g.n) return;
-  const float d2 = g.dist_sq[t];
-  const float sg = (float)g.sign[t];
-  const float root = sqrtf(d2 + 1e-8f);
   const gq3 on = gq_mk(g.onrm[t * 3], g.onrm[t * 3 + 1], g.onrm[t * 3 + 2]);
-  const gq3 vC = sg * on;  // outward object normal (object_model.py:246)
   const gq3 nH = gq_mk(g.cnrm[t * 3], g.cnrm[t * 3 + 1], g.cnrm[t * 3 + 2]);
-  const float e = expf(1.0f + gq_dot(vC, nH));  // (1 - sum((-vC) nH)).exp()
-  g.obj_normal[t * 3] = vC.x;
-  g.obj_normal[t * 3 + 1] = vC.y;
-  g.obj_normal[t * 3 + 2] = vC.z;
-  // E_dis term = e * |distance| = e * root ; d root / d p = (p - closest)/root
-  const gq3 diff = gq_mk(g.cpts[t * 3] - g.closest[t * 3], g.cpts[t * 3 + 1] - g.closest[t * 3 + 1],
-                         g.cpts[t * 3 + 2] - g.closest[t * 3 + 2]);
-  const float s = g.w_dis * e / root;
-  g.g_cpts[t * 3] = s * diff.x;
-  g.g_cpts[t * 3 + 1] = s * diff.y;
-  g.g_cpts[t * 3 + 2] = s * diff.z;
-  const float s2 = g.w_dis * e * root;
-  g.g_cnrm[t * 3] = s2 * vC.x;
-  g.g_cnrm[t * 3 + 1] = s2 * vC.y;
-  g.g_cnrm[t * 3 + 2] = s2 * vC.z;
+  const gq3 p = gq_mk(g.cpts[t * 3], g.cpts[t * 3 + 1], g.cpts[t * 3 + 2]);
+  const gq3 cl = gq_mk(g.closest[t * 3], g.closest[t * 3 + 1], g.closest[t * 3 + 2]);
+  const GqContactTerm c = gq_contact_term(g.dist_sq[t], (float)g.sign[t], on, nH, p, cl, g.w_dis);
+  g.obj_normal[t * 3] = c.vC.x;
+  g.obj_normal[t * 3 + 1] = c.vC.y;
+  g.obj_normal[t * 3 + 2] = c.vC.z;
+  g.g_cpts[t * 3] = c.g_p.x;
+  g.g_cpts[t * 3 + 1] = c.g_p.y;
+  g.g_cpts[t * 3 + 2] = c.g_p.z;
+  g.g_cnrm[t * 3] = c.g_n.x;
+  g.g_cnrm[t * 3 + 1] = c.g_n.y;
+  g.g_cnrm[t * 3 + 2] = c.g_n.z;
 }
 
 // stage 2: per-row reductions; one block of 256 threads per row (deterministic tree reduction)

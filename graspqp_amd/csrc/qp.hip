@@ -229,6 +229,32 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
   return GQ_OK;
 }
 
+// internal (fcstep.hip): table pointers inside a box-QP workspace, and the stand-alone stop-rule launch
+int gq_qp_tables_(void* workspace, size_t workspace_bytes, int B, int nz, int max_iter, float** resid, float** mu,
+                  float** snap, float** runmin, int** kstar) {
+  GQ_REQUIRE(workspace && B > 0 && nz > 0 && max_iter >= 1 && max_iter <= 64, "qp_tables: bad arguments");
+  GqQpWs w = gq_qp_carve(workspace, B, nz, max_iter);
+  GQ_REQUIRE(workspace_bytes >= w.total, "boxqp: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  *resid = w.resid;
+  *mu = w.mu;
+  *snap = w.snap;
+  *runmin = w.runmin;
+  *kstar = w.kstar;
+  return GQ_OK;
+}
+int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
+                       float* runmin, int* kstar, int32_t* n_iter, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B <= GQ_STOP_MAXB && max_iter <= GQ_STOP_MAXIT)
+    hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, resid, mu, B, max_iter, eps,
+                       not_improved_lim, runmin, kstar, n_iter);
+  else
+    hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, resid, mu, B, max_iter, eps, not_improved_lim,
+                       runmin, kstar, n_iter);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
 // internal (fc.hip): run the iterations and the stop rule only; the caller picks each row's best iterate itself
 int gq_lsq_boxqp_iterate_(const float* A, float lower_s, float upper_s, int64_t batch, int m, int nz, float ridge,
                           float eps, int max_iter, int32_t* n_iter, void* workspace, size_t workspace_bytes,

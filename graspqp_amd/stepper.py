@@ -121,15 +121,11 @@ class GraspStepper:
         e_fc = self.terms_new[1]
         C("gq_sdf_forward_meshset", self.objs.handle, f32(self.cpts), B * n, self.be * n, f32(self.d2), i32(self.sgn),
           f32(self.onrm), f32(self.closest), st)
-        C("gq_contact_terms", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.closest), f32(self.cpts),
-          f32(self.cnrm), B, n, float(w["E_dis"]), f32(self.obj_normal), f32(self.g_cpts), f32(self.g_cnrm), st)
-        C("gq_fc_forward", f32(self.cpts), f32(self.obj_normal), f32(self.cog), B, n, int(fc["n_cone_vecs"]),
-          float(fc["friction"]), float(fc["torque_weight"]), float(fc["max_limit"]), float(fc["svd_gain"]),
-          float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]), f32(e_fc), f32(self.x_sum), i32(self.n_iter),
-          _C.ptr(self.fc_ws), self.fc_nb, st)
-        C("gq_fc_backward", f32(self.cpts), f32(self.obj_normal), f32(self.cog), f32(self.w_fc_vec), B, n,
-          int(fc["n_cone_vecs"]), float(fc["friction"]), float(fc["torque_weight"]), float(fc["svd_gain"]),
-          float(fc["values_gain"]), 1, f32(self.g_cpts), _C.ptr(self.fc_ws), self.fc_nb, st)
+        C("gq_fc_step", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.closest), f32(self.cpts), f32(self.cnrm),
+          f32(self.cog), B, n, int(fc["n_cone_vecs"]), float(fc["friction"]), float(fc["torque_weight"]),
+          float(fc["max_limit"]), float(fc["svd_gain"]), float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]),
+          float(w["E_dis"]), float(w["E_fc"]), f32(self.obj_normal), f32(self.g_cpts), f32(self.g_cnrm), f32(e_fc),
+          f32(self.x_sum), i32(self.n_iter), _C.ptr(self.fc_ws), self.fc_nb, st)
 
     def _eval_pen(self, pose, st, timer=None):
         """Hand-penetration query (the roofline kernel of bench.py) + its backward.  ``timer`` = HIP event pair around

@@ -86,6 +86,17 @@ int gq_fc_backward(const float* contact_pts, const float* contact_normals, const
                    void* workspace, size_t workspace_bytes, void* stream);
 int gq_fc_peek(void* workspace, size_t workspace_bytes, int64_t batch, int n_contact, int n_cone, const float** F,
                const float** x, const float** val, const float** svd);
+/* Fused form of gq_contact_terms + gq_fc_forward + gq_fc_backward for constant upstream weights (the MALA* loop,
+ * scripts/fit.py:434-438: w_dis on E_dis, w_fc on E_fc): two launches per iteration instead of nine, the grasp matrix
+ * stays in registers between the cone construction and the QP iterations, and qpth's batch-global stop rule is
+ * replayed inside the second kernel.  Inputs as gq_contact_terms; g_contact_pts receives w_dis dE_dis/dp +
+ * w_fc dE_fc/dp, g_hand_normals w_dis dE_dis/dnH.  Workspace: gq_fc_workspace_bytes; gq_fc_peek works afterwards. */
+int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, const float* closest,
+               const float* contact_pts, const float* hand_normals, const float* cog, int64_t batch, int n_contact,
+               int n_cone, float friction, float torque_weight, float max_limit, float svd_gain, float values_gain,
+               float eps, int max_iter, float w_dis, float w_fc, float* obj_normal, float* g_contact_pts,
+               float* g_hand_normals, float* e_fc, float* x_sum, int32_t* n_iter, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* ---- hand kinematics: HandModel.set_parameters / fk / _set_contact_idxs -----------------------------
  * reference: core/hand_model.py:762-766,787-873,1220-1267  utils/transforms.py:5-13

@@ -244,6 +244,8 @@ struct GqPenArgs {
   const int32_t* sub_off;  // (L+1)
   const float* occ_invz;   // (L) 32 / z-extent of the link AABB (x, y scales ride in the pads of aabb)
   const uint32_t* occ;     // (L, 32*32) words: bit ix of word iz*32+iy set <=> voxel may contain interior/surface
+  const uint32_t* cand_off;  // (L*32768 + 1) candidate-list offsets per voxel, or null (gq_cand_fill_kernel)
+  const uint16_t* cand_idx;  // face indices (local to the link mesh) that can be closest to some point of the voxel
   int B, P, L, D, batch_each;
   float* dis;     // (B, P)
   int32_t* link;  // (B, P)
@@ -724,6 +726,249 @@ __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
   }
 }
 
+// ---- penetration-only query with per-voxel candidate faces (the hot path of E_pen) -------------------------------
+// One block = 256 surface points of one row, no global queues, no global atomics.
+//   A  every thread walks the links for its point: bounding sphere of the link box (LDS), link frame, AABB, occupancy
+//      bit of the 32^3 voxel.  Only 2e3 .. 3e4 of the 9e6 (point, link) pairs of a config-2 launch survive; a survivor
+//      becomes an ENTRY in LDS and its voxel's candidate faces become ITEMS (entry, j) in LDS.
+//   B  the block's threads share the items evenly: one (point, face) ranking each, all lanes busy, independent gathers
+//      in flight; the minimum per entry is taken with a 64-bit LDS atomicMin on (distance, original face index, face),
+//      which is independent of the processing order.
+//   C  one thread per entry finishes the winner exactly (closest point, sign); penetrating entries compete per point
+//      with a 64-bit LDS atomicMax on (dis, 255 - link, entry) -- the max over links with torch's first-index tie rule.
+//   D  the point's own thread writes dis (every point) and link / gradient (penetrating points only).
+// The candidate list of a voxel holds every face that is closest for SOME point of the voxel (gq_cand_kernel), so the
+// result equals the brute-force scan of the whole link mesh.  Entries / items beyond the LDS capacities are ranked
+// inline by the thread that found them (same arithmetic, just slower).
+#define GQ_PG_ECAP 512
+#define GQ_PG_ICAP 4096
+struct GqPgEntry {
+  float x, y, z;      // point in the link frame
+  uint32_t c0;        // first candidate
+  uint16_t pt, link;  // local point index, link
+};
+__device__ __forceinline__ unsigned long long gq_rank_key(float d2, unsigned orig_local, unsigned f_local) {
+  unsigned b = __float_as_uint(d2);
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving map of floats onto unsigned
+  return ((unsigned long long)b << 32) | ((unsigned long long)(orig_local & 0xffffu) << 16) | (f_local & 0xffffu);
+}
+template <bool EVAL>
+__global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
+  extern __shared__ float s_link[];  // L x 24: link transform (12) + padded AABB (8) + occupancy z scale (1) + pad,
+                                     // then L x 4: bounding sphere of the link box in the hand frame (centre, r^2)
+  __shared__ GqPgEntry s_ent[GQ_PG_ECAP];
+  __shared__ unsigned long long s_ekey[GQ_PG_ECAP];
+  __shared__ float s_ecl[GQ_PG_ECAP * 4];  // closest point (link frame) + dis of the finished entries
+  __shared__ uint32_t s_item[GQ_PG_ICAP];  // entry << 16 | j
+  __shared__ unsigned long long s_pkey[256];
+  __shared__ int s_cnt[2];
+  float* s_sph = s_link + g.L * 24;
+  const int row = blockIdx.y, tid = threadIdx.x;
+  const int pt = blockIdx.x * blockDim.x + tid;
+  if (g.span && tid == 0) gq_span_open(g.span);
+  for (int i = tid; i < g.L * 24; i += blockDim.x) {
+    const int l = i / 24, k = i % 24;
+    float v = 0.0f;
+    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
+    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
+    else if (k == 20) v = g.occ_invz[l];
+    s_link[i] = v;
+  }
+  if (tid < g.L) {
+    const int l = tid;
+    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
+    const float* bb = g.aabb + l * 8;
+    const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
+    const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
+    s_sph[l * 4 + 0] = T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3];
+    s_sph[l * 4 + 1] = T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7];
+    s_sph[l * 4 + 2] = T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11];
+    s_sph[l * 4 + 3] = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
+  }
+  if (tid < 2) s_cnt[tid] = 0;
+  s_pkey[tid] = 0ull;
+  const bool ok = pt < g.P;
+  const int obj = row / g.batch_each;
+  const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
+  const float* hp = g.hand_pose + (size_t)row * g.D;
+  const float* R = g.Rg + (size_t)row * 9;
+  const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+  __syncthreads();
+  // ---- A: scan -------------------------------------------------------------------------------------------------
+  float in_dis = 0.0f;  // result of entries this thread had to rank inline (capacity overflow)
+  int in_link = -1;
+  gq3 in_cl = gq_mk(0, 0, 0), in_xl = gq_mk(0, 0, 0);
+  for (int l = 0; l < g.L; ++l) {
+    // bounding sphere first (one LDS read, 7 VALU ops); the surface points are Morton-ordered, so a wavefront is a
+    // compact patch of the object and most (wavefront, link) pairs end here
+    const float4 sph = *reinterpret_cast<const float4*>(s_sph + l * 4);
+    const gq3 dc = xh - gq_mk(sph.x, sph.y, sph.z);
+    const bool near = ok && gq_dot(dc, dc) <= sph.w;
+    if (__ballot(near) == 0ull) continue;
+    const float* T = s_link + l * 24;
+    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
+    const float* bb = T + 12;
+    if (!(near && gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
+    const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
+    const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
+    if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
+    if (!EVAL) continue;
+    const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
+    const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
+    if (len == 0u) continue;
+    const int e = atomicAdd(&s_cnt[0], 1);
+    int ib = GQ_PG_ICAP;
+    if (e < GQ_PG_ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
+    if (e < GQ_PG_ECAP && ib + (int)len <= GQ_PG_ICAP) {
+      GqPgEntry en;
+      en.x = xl.x; en.y = xl.y; en.z = xl.z;
+      en.c0 = c0;
+      en.pt = (uint16_t)tid;
+      en.link = (uint16_t)l;
+      s_ent[e] = en;
+      s_ekey[e] = ~0ull;
+      for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
+    } else {  // no room: rank the candidates here
+      if (e < GQ_PG_ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
+      const int f0 = g.off[l];
+      float bd = GQ_INF_F;
+      unsigned bo = 0xffffffffu;
+      int bi = -1;
+      for (uint32_t c = c0; c < c0 + len; ++c) {
+        const int f = f0 + (int)g.cand_idx[c];
+        const GqFace fc = g.rec[f];
+        const float d2 = gq_tri_rank(fc, xl - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
+        const unsigned orig = (unsigned)__float_as_int(fc.r5.z);
+        if (d2 < bd || (d2 == bd && orig < bo)) {
+          bd = d2;
+          bo = orig;
+          bi = f;
+        }
+      }
+      const GqSdfOut o = gq_tri_finish(g.rec[bi], xl);
+      const float dis = sqrtf(o.dist2 + 1e-8f);
+      if (o.sign < 0 && dis > in_dis) {
+        in_dis = dis;
+        in_link = l;
+        in_cl = o.closest;
+        in_xl = xl;
+      }
+    }
+  }
+  __syncthreads();
+  const int n_ent = min(s_cnt[0], GQ_PG_ECAP), n_item = min(s_cnt[1], GQ_PG_ICAP);
+  // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
+  for (int i = tid; i < n_item; i += 256) {
+    const uint32_t it = s_item[i];
+    const int e = (int)(it >> 16);
+    const GqPgEntry en = s_ent[e];
+    const int f0 = g.off[en.link];
+    const unsigned fl = g.cand_idx[en.c0 + (it & 0xffffu)];
+    const GqFace fc = g.rec[f0 + (int)fl];
+    const float d2 = gq_tri_rank(fc, gq_mk(en.x - fc.r0.x, en.y - fc.r0.y, en.z - fc.r0.z));
+    const unsigned orig = (unsigned)__float_as_int(fc.r5.z) - (unsigned)f0;  // original index inside the mesh
+    atomicMin(&s_ekey[e], gq_rank_key(d2, orig, fl));
+  }
+  __syncthreads();
+  // ---- C: finish the winner of every entry ----------------------------------------------------------------------
+  for (int e = tid; e < n_ent; e += 256) {
+    const GqPgEntry en = s_ent[e];
+    if (en.c0 == 0xffffffffu) continue;  // was ranked inline
+    const int f = g.off[en.link] + (int)(s_ekey[e] & 0xffffull);
+    const gq3 xl = gq_mk(en.x, en.y, en.z);
+    const GqSdfOut o = gq_tri_finish(g.rec[f], xl);
+    if (o.sign < 0) {  // inside the link: dis = +sqrt(d^2 + 1e-8) > 0
+      const float dis = sqrtf(o.dist2 + 1e-8f);
+      s_ecl[e * 4 + 0] = o.closest.x;
+      s_ecl[e * 4 + 1] = o.closest.y;
+      s_ecl[e * 4 + 2] = o.closest.z;
+      s_ecl[e * 4 + 3] = dis;
+      atomicMax(&s_pkey[en.pt], ((unsigned long long)__float_as_uint(dis) << 32) |
+                                    ((unsigned long long)(255 - (int)en.link) << 16) | (unsigned long long)e);
+    }
+  }
+  __syncthreads();
+  // ---- D: outputs ---------------------------------------------------------------------------------------------------
+  if (ok) {
+    // dis for every point (coalesced 4 B); link and gradient only where a link is penetrated -- nothing downstream
+    // reads them elsewhere (energy.py:59-61 zeroes dis <= 0), the caller provides zero-initialised buffers
+    float best_dis = in_dis;
+    int best_link = in_link;
+    gq3 best_cl = in_cl, best_xl = in_xl;
+    const unsigned long long pk = s_pkey[tid];
+    if (pk != 0ull) {
+      const int e = (int)(pk & 0xffffull);
+      const float dis = s_ecl[e * 4 + 3];
+      const int l = (int)s_ent[e].link;
+      if (dis > best_dis || (dis == best_dis && l < best_link)) {
+        best_dis = dis;
+        best_link = l;
+        best_cl = gq_mk(s_ecl[e * 4], s_ecl[e * 4 + 1], s_ecl[e * 4 + 2]);
+        best_xl = gq_mk(s_ent[e].x, s_ent[e].y, s_ent[e].z);
+      }
+    }
+    const size_t o = (size_t)row * g.P + pt;
+    g.dis[o] = best_link >= 0 ? best_dis : -1e30f;
+    if (best_link >= 0) {
+      const float* T = s_link + best_link * 24;
+      const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+      const gq3 gh = gq_mv(Rl, (1.0f / best_dis) * (best_xl - best_cl));
+      g.link[o] = best_link;
+      g.gvec[o * 3 + 0] = gh.x;
+      g.gvec[o * 3 + 1] = gh.y;
+      g.gvec[o * 3 + 2] = gh.z;
+    }
+  }
+  if (g.span) {
+    __syncthreads();
+    if (tid == 0) gq_span_close(g.span);
+  }
+}
+
+// ---- candidate lists (setup) ----------------------------------------------------------------------------------------
+// Voxel with centre c and half diagonal r: for a point p of the voxel let f* be its closest face and f_c the closest
+// face of c.  |p f*| <= |p f_c| <= |c f_c| + r, hence |c f*| <= |p f*| + r <= d_min(c) + 2r: every face that can win
+// somewhere in the voxel lies within d_min(c) + 2r of the centre (a 1e-5 m margin absorbs rounding and the ranking
+// noise of gq_tri_rank).  FILL = false counts, FILL = true writes the (ascending) face indices.
+template <bool FILL>
+__global__ __launch_bounds__(256) void gq_cand_kernel(const GqFace* __restrict__ rec, const int32_t* __restrict__ off,
+                                                      const float* __restrict__ aabb, const float* __restrict__ invz,
+                                                      const uint32_t* __restrict__ occ, uint32_t* __restrict__ count,
+                                                      const uint32_t* __restrict__ cand_off,
+                                                      uint16_t* __restrict__ cand_idx) {
+  const int m = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;  // 0..32767 = iz*1024 + iy*32 + ix
+  const int ix = v & 31, iy = (v >> 5) & 31, iz = v >> 10;
+  const bool marked = (occ[(size_t)m * 1024 + iz * 32 + iy] >> ix) & 1u;
+  if (!marked) {
+    if (!FILL) count[(size_t)m * 32768 + v] = 0u;
+    return;
+  }
+  const float* bb = aabb + m * 8;
+  const float sx = 1.0f / bb[3], sy = 1.0f / bb[7], sz = 1.0f / invz[m];
+  const gq3 p = gq_mk(bb[0] + ((float)ix + 0.5f) * sx, bb[1] + ((float)iy + 0.5f) * sy, bb[2] + ((float)iz + 0.5f) * sz);
+  const float r = 0.5f * sqrtf(sx * sx + sy * sy + sz * sz);
+  const int f0 = off[m], f1 = off[m + 1];
+  float dmin = GQ_INF_F;
+  for (int f = f0; f < f1; ++f) {
+    const GqFace fc = rec[f];
+    dmin = fminf(dmin, gq_tri_dist2(fc, p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z)));
+  }
+  const float lim = sqrtf(fmaxf(dmin, 0.0f)) + 2.0f * r + 1e-5f;
+  const float lim2 = lim * lim * 1.0001f;
+  uint32_t n = 0;
+  const uint32_t base = FILL ? cand_off[(size_t)m * 32768 + v] : 0u;
+  for (int f = f0; f < f1; ++f) {
+    const GqFace fc = rec[f];
+    if (gq_tri_dist2(fc, p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z)) <= lim2) {
+      if (FILL) cand_idx[base + n] = (uint16_t)(f - f0);
+      ++n;
+    }
+  }
+  if (!FILL) count[(size_t)m * 32768 + v] = n;
+}
+
 // ---- occupancy grid construction (setup) ---------------------------------------------------------------------------
 __global__ void gq_occ_faces_kernel(const GqFace* __restrict__ rec, const int32_t* __restrict__ off, int n_mesh,
                                     const float* __restrict__ aabb, const float* __restrict__ invz,
@@ -789,6 +1034,9 @@ struct gqMeshSet {
   int32_t* cl_off_dev;    // (n_mesh+1)
   uint32_t* occ_dev;   // (n_mesh, 1024) occupancy bits or null (gq_meshset_build_occupancy)
   float* occ_invz_dev; // (n_mesh)
+  uint32_t* cand_off_dev;  // (n_mesh*32768 + 1) per-voxel candidate lists or null (gq_meshset_build_occupancy)
+  uint16_t* cand_idx_dev;
+  int64_t n_cand;
   int n_mesh;
   int64_t n_faces;
 };
@@ -1025,6 +1273,35 @@ int gq_meshset_build_occupancy(gqMeshSet* ms) {
                      ms->occ_invz_dev, ms->occ_dev);
   GQ_LAUNCH_CHECK();
   GQ_CHECK_HIP(hipDeviceSynchronize());
+  // per-voxel candidate faces (only when 16-bit local face indices suffice)
+  bool small = true;
+  for (int m = 0; m < n; ++m) small = small && (ms->off_host[m + 1] - ms->off_host[m] < 65536);
+  if (small) {
+    const size_t nv = (size_t)n * 32768;
+    uint32_t* cnt_dev = nullptr;
+    GQ_CHECK_HIP(hipMalloc(&cnt_dev, sizeof(uint32_t) * nv));
+    hipLaunchKernelGGL(gq_cand_kernel<false>, dim3(128, (unsigned)n), dim3(256), 0, 0, ms->rec, ms->off_dev, ms->aabb_dev,
+                       ms->occ_invz_dev, ms->occ_dev, cnt_dev, nullptr, nullptr);
+    GQ_LAUNCH_CHECK();
+    std::vector<uint32_t> cnt(nv), offs(nv + 1);
+    GQ_CHECK_HIP(hipMemcpy(cnt.data(), cnt_dev, sizeof(uint32_t) * nv, hipMemcpyDeviceToHost));
+    GQ_CHECK_HIP(hipFree(cnt_dev));
+    uint64_t run = 0;
+    for (size_t i = 0; i < nv; ++i) {
+      offs[i] = (uint32_t)run;
+      run += cnt[i];
+    }
+    GQ_REQUIRE(run < (1ull << 32), "meshset_build_occupancy: candidate lists too long");
+    offs[nv] = (uint32_t)run;
+    ms->n_cand = (int64_t)run;
+    GQ_CHECK_HIP(hipMalloc(&ms->cand_off_dev, sizeof(uint32_t) * (nv + 1)));
+    GQ_CHECK_HIP(hipMalloc(&ms->cand_idx_dev, sizeof(uint16_t) * (run + 1)));
+    GQ_CHECK_HIP(hipMemcpy(ms->cand_off_dev, offs.data(), sizeof(uint32_t) * (nv + 1), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gq_cand_kernel<true>, dim3(128, (unsigned)n), dim3(256), 0, 0, ms->rec, ms->off_dev, ms->aabb_dev,
+                       ms->occ_invz_dev, ms->occ_dev, nullptr, ms->cand_off_dev, ms->cand_idx_dev);
+    GQ_LAUNCH_CHECK();
+    GQ_CHECK_HIP(hipDeviceSynchronize());
+  }
   return GQ_OK;
 }
 
@@ -1039,6 +1316,8 @@ int gq_meshset_destroy(gqMeshSet* ms) {
   (void)hipFree(ms->cl_off_dev);
   if (ms->occ_dev) (void)hipFree(ms->occ_dev);
   if (ms->occ_invz_dev) (void)hipFree(ms->occ_invz_dev);
+  if (ms->cand_off_dev) (void)hipFree(ms->cand_off_dev);
+  if (ms->cand_idx_dev) (void)hipFree(ms->cand_idx_dev);
   delete[] ms->off_host;
   delete ms;
   return GQ_OK;
@@ -1146,6 +1425,8 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   a.sub_off = links->sub_off_dev;
   a.occ = links->occ_dev;
   a.occ_invz = links->occ_invz_dev;
+  a.cand_off = links->cand_off_dev;
+  a.cand_idx = links->cand_idx_dev;
   a.B = (int)(n_obj * batch_each);
   a.P = (int)n_surface;
   a.L = links->n_mesh;
@@ -1163,8 +1444,15 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     e0 = ((hipEvent_t*)timer)[0];
     e1 = ((hipEvent_t*)timer)[1];
   }
-  if (penetration_only == 1 && workspace != nullptr) {
-    // queue-based, load-balanced path (see gq_pen_scan_kernel)
+  if (penetration_only == 1 && a.occ && a.cand_off) {
+    // one pass over the (point, link) pairs, candidate faces from the voxel grid (see gq_pen_grid_kernel)
+    hipExtLaunchKernelGGL(gq_pen_grid_kernel<true>, grid, dim3(256), (size_t)a.L * 28 * sizeof(float),
+                          (hipStream_t)stream, e0, e1, 0, a);
+  } else if (penetration_only == 9 && a.occ && a.cand_off) {  // diagnostics: the scan without candidate evaluation
+    hipExtLaunchKernelGGL(gq_pen_grid_kernel<false>, grid, dim3(256), (size_t)a.L * 28 * sizeof(float),
+                          (hipStream_t)stream, e0, e1, 0, a);
+  } else if ((penetration_only == 1 || penetration_only == 3) && workspace != nullptr) {
+    // queue-based, load-balanced path without candidate lists (see gq_pen_scan_kernel); 3 forces it for A/B tests
     const size_t cap_link = (size_t)a.B * a.P;
     const size_t cap = cap_link * a.L;
     const size_t need = 1024 + cap * sizeof(GqPenItem) + (size_t)a.B * a.P * 8;
@@ -1182,7 +1470,7 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     hipLaunchKernelGGL(gq_pen_eval_kernel, dim3(GQ_PEN_EVAL_BLOCKS), dim3(512), 0, (hipStream_t)stream, a, q);
     GQ_LAUNCH_CHECK();
     hipExtLaunchKernelGGL(gq_pen_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, nullptr, e1, 0, a, q);
-  } else if (penetration_only == 1)
+  } else if (penetration_only == 1 || penetration_only == 3)
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   else if (penetration_only == 2)  // AABB test only, no occupancy grid (kept for A/B tests)
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);

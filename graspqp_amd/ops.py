@@ -407,10 +407,10 @@ class _HandPen(torch.autograd.Function):
         B = hp.shape[0]
         dev = hp.device
         dis = torch.empty(B, P, device=dev)
-        link = torch.empty(B, P, dtype=torch.int32, device=dev)
-        gvec = torch.empty(B, P, 3, device=dev)
+        link = torch.zeros(B, P, dtype=torch.int32, device=dev)  # mode 1 writes link / gvec only where dis > 0
+        gvec = torch.zeros(B, P, 3, device=dev)
         pws, pnb = None, 0
-        if int(penetration_only) == 1:
+        if int(penetration_only) == 3:  # queue path without candidate lists (kept for A/B tests)
             pnb = _size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), hand.L)
             pws = torch.zeros(pnb, dtype=torch.uint8, device=dev)  # queue counters must start at zero
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],

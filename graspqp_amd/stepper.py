@@ -87,8 +87,10 @@ class GraspStepper:
         self.fc_nb = ops._size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, int(self.fc["n_cone_vecs"]),
                                     int(self.fc["max_iter"]))
         self.fc_ws = ops._ws(self.fc_nb, self.dev)
-        self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
-        self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)  # queue counters start at zero
+        self.pen_nb, self.pen_ws = 0, None
+        if int(penetration_only) == 3:  # queue path of the penetration query (A/B tests); counters start at zero
+            self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
+            self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)
         self._graph = None
         self.kernel_events = None
         self._span = torch.zeros(64, 2, dtype=torch.int64, device=self.dev)
@@ -132,11 +134,10 @@ class GraspStepper:
         the query (hipExtLaunchKernelGGL start/stop events).  The query also records its own execution span in
         100 MHz s_memrealtime ticks (64 shards of {min block start, max block end}); the backward launch folds them
         into ``_span_acc`` = {sum, launches}, which works inside a hipGraph replay too."""
-        fused = self.penetration_only == 1
         _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
                 _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
                 _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
-                _C.ptr(self.pen_ws) if fused else None, self.pen_nb, timer, _C.ptr(self._span), st)
+                _C.ptr(self.pen_ws), self.pen_nb, timer, _C.ptr(self._span), st)
         _C.call("gq_hand_pen_backward", self.L, _C.f32(self.surf), self.n_obj, self.P, self.be, _C.f32(pose), self.D,
                 _C.f32(self.Rg), None, _C.i32(self.pen_link), _C.f32(self.pen_gvec), _C.f32(self.wrench), _C.f32(self.gRt),
                 _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),

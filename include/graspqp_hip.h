@@ -156,8 +156,12 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
 /* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
  * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.
  * dis (B,P) = max over links of sqrt(d^2 + 1e-8) * (-sign); link (B,P) argmax; gvec (B,P,3) = d dis / d x_h.
- * penetration_only = 0: dis exact everywhere.  = 1: only links whose AABB contains the point are evaluated, so
- * dis is exact where it is > 0 (all that E_pen uses, energy.py:59-61) and merely <= 0 elsewhere.           */
+ * penetration_only = 0: dis exact everywhere.
+ * penetration_only = 1: what E_pen uses (energy.py:59-61 zeroes dis <= 0): dis is exact where it is > 0 and -1e30
+ *   elsewhere; link / gvec are WRITTEN ONLY where dis > 0 (pass zero-initialised buffers).  Per link a point is looked
+ *   up in the 32^3 voxel grid of the link mesh (gq_meshset_build_occupancy) and only the voxel's candidate faces are
+ *   ranked.  = 2: AABB culling only, = 3: occupancy grid + load-balancing queues (needs the workspace) -- both kept
+ *   for A/B tests; they write link / gvec everywhere.                                                          */
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (n_obj,P,3) */, int64_t n_obj,
                         int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                         const float* link_T, int penetration_only, float* dis, int32_t* link, float* gvec,

@@ -1,8 +1,8 @@
-"""GPU micro-benchmark of the hand-penetration kernel variants on a frozen chain state (A/B in one process)."""
-import os, sys, time
+"""GPU micro-benchmark / diagnostics of the hand-penetration query on a frozen chain state (development aid)."""
+import ctypes, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from graspqp_amd import ops, _C
 from graspqp_amd.hands import get_hand_spec
 from graspqp_amd.stepper import GraspStepper
@@ -20,33 +20,40 @@ for warm in [int(a) for a in sys.argv[1:]] or [20, 200, 1000]:
     while done < warm:
         st.step(); done += 1
     torch.cuda.synchronize()
-    # freeze: evaluate pre-stage on current accepted state
-    st._eval_pre(st.hand_pose, st.contact_idx, _C.stream_ptr())
+    s = _C.stream_ptr()
+    s_side = torch.cuda.Stream()
+    st._eval_fk(st.hand_pose, st.contact_idx, s)
+    def fwd(mode, ws):
+        _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(st.surf), st.n_obj, st.P, st.be, _C.f32(st.hand_pose), st.D,
+                _C.f32(st.Rg), _C.f32(st.link_T), mode, _C.f32(st.pen_dis), _C.i32(st.pen_link), _C.f32(st.pen_gvec),
+                _C.ptr(ws_t) if ws else None, nb if ws else 0, None, None, _C.stream_ptr())
     res = {}
-    for mode in (2, 3, 1, 0):
-        st.penetration_only = 1 if mode == 3 else mode
-        ws_keep = st.pen_ws
-        if mode == 3: st.pen_ws = None  # single-kernel occupancy path
-        for _ in range(3): st._eval_pen(st.hand_pose, _C.stream_ptr())
+    nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(st.B), ctypes.c_int64(st.P), st.L)
+    ws_t = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    ref = None
+    for name, mode, ws in (("grid", 1, False), ("queue", 3, True), ("scanonly", 9, False)):
+        for _ in range(3): fwd(mode, ws)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20): st._eval_pen(st.hand_pose, _C.stream_ptr())
+        g = torch.cuda.CUDAGraph()   # replay from a graph: the ctypes call costs more host time than the kernel
+        with torch.cuda.graph(g):
+            for _ in range(20): fwd(mode, ws)
+        g.replay(); torch.cuda.synchronize()
+        e0.record()
+        g.replay()
         e1.record(); torch.cuda.synchronize()
-        res[mode] = e0.elapsed_time(e1) / 20 * 1e3
-        st.pen_ws = ws_keep
-        if mode == 2: ref = st.pen_dis.clone()
+        res[name] = e0.elapsed_time(e1) / 20 * 1e3
+        if name == "scanonly": continue
+        if ref is None: ref = (st.pen_dis.clone(), st.pen_link.clone(), st.pen_gvec.clone())
         else:
-            pos = ref > 1e-6
-            err = (st.pen_dis[pos]-ref[pos]).abs().max().item(); assert err < 3e-5, (mode, err)
+            pos = ref[0] > 1e-6
+            print(f"   {name}: max |dis - grid| on positives {(st.pen_dis[pos] - ref[0][pos]).abs().max().item():.2e}, "
+                  f"positives {int(pos.sum())} vs {int((st.pen_dis > 1e-6).sum())}")
     cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
-    import ctypes
-    for mode in (2, 1):
-        cnt.zero_(); st.penetration_only = mode
-        _C.call("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
-        st._eval_pen(st.hand_pose, _C.stream_ptr()); torch.cuda.synchronize()
-        _C.call("gq_debug_set_pen_counters", None)
-        print(f"   mode {mode}: needing pairs {int(cnt[0])}, (wave,link) evals {int(cnt[1])} of {10240*14}, (wave,sub) evals {int(cnt[2])} -> faces/wave-eval {16*int(cnt[2])/max(int(cnt[1]),1):.0f}")
-    npos = int((ref > 0).sum())
-    print(f"after {done:5d} steps: AABB only {res[2]:7.1f} us | occupancy grid {res[3]:7.1f} us | +queue {res[1]:7.1f} us | exact {res[0]:7.1f} us | penetrating points {npos} / {ref.numel()}  mean E {st.energy.mean().item():.2f}")
-    st.penetration_only = 1
+    _C.call("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
+    fwd(3, False); torch.cuda.synchronize()
+    _C.call("gq_debug_set_pen_counters", None)
+    npos = int((st.pen_dis > 0).sum())
+    print(f"after {done:5d} steps: grid {res['grid']:.1f} us | queue {res['queue']:.1f} us | scan only {res['scanonly']:.1f} us | "
+          f"(point,link) pairs in occupied voxels {int(cnt[0])} of {256*2500*14}, penetrating points {npos}, mean E {st.energy.mean().item():.2f}")

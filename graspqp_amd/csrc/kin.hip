@@ -11,6 +11,7 @@ struct gqHand {
   int J, L, C, S, NG, max_depth;
   int32_t *node_parent, *node_type, *link_node, *cand_link, *sphere_link, *group_off;
   int32_t *node_depth, *child_off, *child_idx;  // tree levels and per-node child lists (wave-parallel FK)
+  int32_t* sphere_grp;                          // (S) group (= link run) of every penetration sphere
   float *node_pre, *node_axis, *link_offset, *cand_pos, *cand_nrm, *sphere, *jlo, *jhi;
 };
 
@@ -101,12 +102,27 @@ struct GqFkArgs {
   float* cpts;      // (B, n, 3)
   float* cnrm;      // (B, n, 3)
   float* spheres;   // (B, S, 3) or null
+  float* e_spen;    // (B) or null: self penetration of the spheres rides along (needs spheres)
+  float* g_spheres; // (B, S, 3): spen_scale * dE_spen / d centre
+  float spen_scale;
 };
+
+// order-preserving map of floats onto unsigned (and back)
+__device__ __forceinline__ unsigned gq_f2o(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float gq_o2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
 
 // one wavefront per row: lane j owns joint node j, then link j, then contacts / spheres j, j+64, ...
 __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ float sW[64 * 12];
   __shared__ float sT[64 * 12];
+  __shared__ float sC[256 * 3];             // world sphere centres (self penetration)
+  __shared__ unsigned long long sKey[64];   // per sphere group: (pen, a, b) of the most penetrating pair
+  __shared__ float sRad[256];
   const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
   const float* hp = g.hand_pose + (size_t)row * g.D;
@@ -160,6 +176,77 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
       const gq3 pw = gq_mv(R, ph) + tg;
       float* o = g.spheres + ((size_t)row * h.S + sidx) * 3;
       o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+      if (g.e_spen) {
+        sC[sidx * 3] = pw.x; sC[sidx * 3 + 1] = pw.y; sC[sidx * 3 + 2] = pw.z;
+      }
+    }
+  }
+  if (g.e_spen) {
+    // Self penetration (hand_model.py:989-1040) on the centres just computed: for every sphere group (= link) the most
+    // penetrating pair against all LATER groups.  Lanes take the partners b of one sphere a at a time; the per-group
+    // minimum is a 64-bit LDS atomicMin on (pen, a, b) -- the first minimal pair in (a, b) order, like a serial scan.
+    const int ng = min(h.NG - 1, 64);  // the last group has nothing after it
+    sKey[lane] = ~0ull;
+    for (int sidx = lane; sidx < h.S; sidx += GQ_WAVE) {
+      sRad[sidx] = h.sphere[sidx * 4 + 3];
+    }
+    __syncthreads();
+    // four lanes per group (16 groups per pass): lane (g, q) scans the pairs (a in g) x (b = first later sphere + q,
+    // + 4, ...), everything from LDS; the four partial minima of a group meet through two quad DPP steps on the
+    // (pen, a, b) key, whose order is the serial scan's order.
+    for (int g0 = 0; g0 < ng; g0 += 16) {
+      const int gi = g0 + (lane >> 2), q = lane & 3;
+      unsigned long long key = ~0ull;
+      if (gi < ng) {
+        const int a0 = h.group_off[gi], a1 = h.group_off[gi + 1];
+        for (int a = a0; a < a1; ++a) {
+          const gq3 pa = gq_mk(sC[a * 3], sC[a * 3 + 1], sC[a * 3 + 2]);
+          const float ra = sRad[a];
+#pragma unroll 4
+          for (int b = a1 + q; b < h.S; b += 4) {
+            const gq3 d = gq_mk(pa.x - sC[b * 3] + 1e-13f, pa.y - sC[b * 3 + 1] + 1e-13f, pa.z - sC[b * 3 + 2] + 1e-13f);
+            const float pen = sqrtf(gq_dot(d, d)) - (ra + sRad[b]);
+            const unsigned long long k =
+                ((unsigned long long)gq_f2o(pen) << 32) | ((unsigned long long)a << 16) | (unsigned long long)b;
+            key = k < key ? k : key;
+          }
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int lo = (int)(key & 0xffffffffull), hi = (int)(key >> 32);
+        const int olo = st == 0 ? __builtin_amdgcn_mov_dpp(lo, 0xb1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(lo, 0x4e, 0xf, 0xf, true);
+        const int ohi = st == 0 ? __builtin_amdgcn_mov_dpp(hi, 0xb1, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(hi, 0x4e, 0xf, 0xf, true);
+        const unsigned long long other = ((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo;
+        key = other < key ? other : key;
+      }
+      if (gi < ng && q == 0) sKey[gi] = key;
+    }
+    __syncthreads();
+    // energy: fixed DPP tree over the groups; gradient: lane s collects, in group order, what lands on sphere s
+    float e = 0.0f;
+    if (lane < ng) {
+      const unsigned long long k = sKey[lane];
+      const float best = gq_o2f((unsigned)(k >> 32));
+      if (k != ~0ull && best < 0.0f) e = -best;
+    }
+    e = gq_dpp_sum(e);
+    if (lane == 0) g.e_spen[row] = e;
+    for (int sidx = lane; sidx < h.S; sidx += GQ_WAVE) {
+      gq3 acc = gq_mk(0, 0, 0);
+      for (int gi = 0; gi < ng; ++gi) {
+        const unsigned long long k = sKey[gi];
+        const float best = gq_o2f((unsigned)(k >> 32));
+        const int ba = (int)((k >> 16) & 0xffffull), bb = (int)(k & 0xffffull);
+        if (k == ~0ull || !(best < 0.0f) || (ba != sidx && bb != sidx)) continue;
+        const gq3 d = gq_mk(sC[ba * 3] - sC[bb * 3] + 1e-13f, sC[ba * 3 + 1] - sC[bb * 3 + 1] + 1e-13f,
+                            sC[ba * 3 + 2] - sC[bb * 3 + 2] + 1e-13f);
+        // E += -|a-b| + ... : dE/da = -(a-b)/|a-b|, dE/db = +(a-b)/|a-b|
+        const float sc = g.spen_scale / sqrtf(gq_dot(d, d)) * (ba == sidx ? -1.0f : 1.0f);
+        acc = acc + sc * d;
+      }
+      float* o = g.g_spheres + ((size_t)row * h.S + sidx) * 3;
+      o[0] = acc.x; o[1] = acc.y; o[2] = acc.z;
     }
   }
 }
@@ -489,6 +576,15 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
   rc |= gq_upload(&h->jhi, d->joints_upper, h->J);
   rc |= gq_upload(&h->group_off, (const int32_t*)groups, (size_t)ng + 1);
   {
+    int32_t grp[256];
+    int gcur = 0;
+    for (int s = 0; s < d->n_spheres; ++s) {
+      while (gcur + 1 < ng && s >= groups[gcur + 1]) ++gcur;
+      grp[s] = gcur;
+    }
+    rc |= gq_upload(&h->sphere_grp, (const int32_t*)grp, (size_t)h->S);
+  }
+  {
     int32_t depth[64], coff[65], cidx[64];
     int md = 0;
     for (int j = 0; j < h->J; ++j) {
@@ -516,7 +612,7 @@ int gq_hand_destroy(gqHand* h) {
   if (!h) return GQ_OK;
   void* p[] = {h->node_parent, h->node_type, h->node_pre, h->node_axis, h->link_node, h->link_offset, h->cand_pos,
                h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off, h->node_depth,
-               h->child_off, h->child_idx};
+               h->child_off, h->child_idx, h->sphere_grp};
   for (void* q : p)
     if (q) (void)hipFree(q);
   delete h;
@@ -532,8 +628,11 @@ int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes) {
 
 int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                   float* Rg, float* link_T, float* contact_points, float* contact_normals, float* sphere_centers,
-                  void* workspace, size_t workspace_bytes, void* stream) {
+                  float spen_scale, float* e_spen, float* g_sphere_centers, void* workspace, size_t workspace_bytes,
+                  void* stream) {
   GQ_REQUIRE(h && hand_pose && Rg && link_T && workspace, "fk_forward: null pointer");
+  GQ_REQUIRE(!e_spen || (sphere_centers && g_sphere_centers && h->S > 0 && h->S <= 256),
+             "fk_forward: the fused self-penetration term needs sphere_centers and g_sphere_centers");
   GQ_REQUIRE(batch > 0 && n_contact >= 0, "fk_forward: bad sizes");
   GQ_REQUIRE(n_contact == 0 || (contact_idx && contact_points && contact_normals), "fk_forward: null contact buffers");
   GQ_REQUIRE(workspace_bytes >= (size_t)batch * h->J * 18 * sizeof(float), "fk_forward: workspace too small");
@@ -550,6 +649,9 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
   a.cpts = contact_points;
   a.cnrm = contact_normals;
   a.spheres = sphere_centers;
+  a.e_spen = e_spen;
+  a.g_spheres = g_sphere_centers;
+  a.spen_scale = spen_scale;
   hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;

@@ -108,14 +108,17 @@ class GraspStepper:
         self._row_energy = e
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
-    # Four pieces: FK, then three independent branches (contacts -> object SDF -> E_fc fwd+bwd | hand penetration
-    # fwd+bwd | self penetration), then FK backward with the row energies.  ``_evaluate`` runs the branches on three
+    # Four pieces: FK (+ self penetration), then two independent branches (contacts -> object SDF -> E_fc fwd+bwd |
+    # hand penetration fwd+bwd), then FK backward with the row energies.  ``_evaluate`` runs the branches on two
     # streams when ``fork`` is set (inside a hipGraph capture they become parallel graph branches).
     def _eval_fk(self, pose, idx, st):
         B, n = self.B, self.n
         _C.call("gq_fk_forward", self.hand.handle, _C.f32(pose), _C.i64(idx), B, n, _C.f32(self.Rg), _C.f32(self.link_T),
-                _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None, _C.ptr(self.fk_ws),
-                self.fk_nb, st)
+                _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None,
+                float(self.w["E_spen"]), _C.f32(self.terms_new[3]) if self.S > 0 else None,
+                _C.f32(self.g_sph_w) if self.S > 0 else None, _C.ptr(self.fk_ws), self.fk_nb, st)
+        if self.S == 0:
+            _C.call("gq_fill", _C.f32(self.terms_new[3]), 0.0, self.B, st)
 
     def _eval_contacts(self, st):
         B, n, w, fc = self.B, self.n, self.w, self.fc
@@ -143,14 +146,6 @@ class GraspStepper:
                 _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),
                 _C.ptr(self._span_acc), st)
 
-    def _eval_spen(self, st):
-        e_spen = self.terms_new[3]
-        if self.S > 0:
-            _C.call("gq_self_pen_forward", self.hand.handle, _C.f32(self.spheres), self.B, float(self.w["E_spen"]),
-                    _C.f32(e_spen), _C.f32(self.g_sph_w), st)
-        else:
-            _C.call("gq_fill", _C.f32(e_spen), 0.0, self.B, st)
-
     def _eval_tail(self, pose, idx, st):
         B, n = self.B, self.n
         f32 = _C.f32
@@ -164,17 +159,13 @@ class GraspStepper:
         if not fork:
             self._eval_contacts(st)
             self._eval_pen(pose, st, timer)
-            self._eval_spen(st)
         else:
             main = torch.cuda.current_stream()
-            sb, sc = self._side
+            sb = self._side
             sb.wait_stream(main)
-            sc.wait_stream(main)
             self._eval_contacts(st)
             self._eval_pen(pose, ctypes.c_void_p(sb.cuda_stream), timer)
-            self._eval_spen(ctypes.c_void_p(sc.cuda_stream))
             main.wait_stream(sb)
-            main.wait_stream(sc)
         self._eval_tail(pose, idx, st)
 
     def evaluate(self, pose, idx):
@@ -279,7 +270,7 @@ class GraspStepper:
                                      self.step_count, self.terms, self._span_acc)]
         rng = (self.gen.get_state(), self._draw_pos)
         if self._side is None:
-            self._side = (torch.cuda.Stream(), torch.cuda.Stream())
+            self._side = torch.cuda.Stream()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         self.draw()

@@ -124,7 +124,9 @@ int gq_hand_destroy(gqHand* h);
 int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes);
 int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx /* (B,n) */, int64_t batch,
                   int n_contact, float* Rg /* (B,9) */, float* link_T /* (B,L,12) */, float* contact_points /* (B,n,3) */,
-                  float* contact_normals /* (B,n,3) */, float* sphere_centers /* (B,S,3) or NULL */, void* workspace,
+                  float* contact_normals /* (B,n,3) */, float* sphere_centers /* (B,S,3) or NULL */,
+                  float spen_scale, float* e_spen /* (B) or NULL: gq_self_pen_forward fused in */,
+                  float* g_sphere_centers /* (B,S,3), with e_spen: spen_scale * dE_spen/dcentre */, void* workspace,
                   size_t workspace_bytes, void* stream);
 /* Optional tail of gq_fk_backward: E_dis, E_joints (with its gradient) and the weighted total of one row
  * (core/energy.py:25-28,47-54; scripts/fit.py:434-438), so the iteration needs no separate reduction launch.     */

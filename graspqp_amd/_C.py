@@ -78,6 +78,23 @@ class RowEnergyDesc(ctypes.Structure):
         (k, ctypes.c_void_p) for k in ("e_dis", "e_joints", "total")]
 
 
+def _struct(name, fields):
+    ty = {"p": ctypes.c_void_p, "i": ctypes.c_int32, "l": ctypes.c_int64, "f": ctypes.c_float, "z": ctypes.c_size_t}
+    return type(name, (ctypes.Structure,), {"_fields_": [(n, ty[t]) for n, t in fields]})
+
+
+# field order = include/graspqp_hip.h
+FcStepDesc = _struct("FcStepDesc", [
+    ("dist_sq", "p"), ("sign", "p"), ("obj_dir", "p"), ("closest", "p"), ("contact_pts", "p"), ("hand_normals", "p"),
+    ("cog", "p"), ("batch", "l"), ("n_contact", "i"), ("n_cone", "i"), ("friction", "f"), ("torque_weight", "f"),
+    ("max_limit", "f"), ("svd_gain", "f"), ("values_gain", "f"), ("eps", "f"), ("max_iter", "i"), ("w_dis", "f"),
+    ("w_fc", "f"), ("obj_normal", "p"), ("g_contact_pts", "p"), ("g_hand_normals", "p"), ("e_fc", "p"), ("x_sum", "p"),
+    ("n_iter", "p"), ("workspace", "p"), ("workspace_bytes", "z")])
+PenStepDesc = _struct("PenStepDesc", [
+    ("links", "p"), ("surface_points", "p"), ("n_obj", "l"), ("n_surface", "l"), ("batch_each", "l"), ("hand_pose", "p"),
+    ("pose_dim", "i"), ("Rg", "p"), ("link_T", "p"), ("dis", "p"), ("link", "p"), ("gvec", "p"), ("link_wrench", "p"),
+    ("gRt", "p"), ("w_pen", "f"), ("e_pen", "p"), ("span", "p"), ("span_acc", "p")])
+
 _lib = None
 _protos = None
 

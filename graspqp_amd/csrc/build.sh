@@ -9,14 +9,14 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 OBJS=()
 deps() {  # headers each translation unit includes
   case "$1" in
-    qp_lr|fcstep) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h" ;;
+    qp_lr|fcstep|stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h" ;;
     qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
-    sdf) echo "common.h tri.h" ;;
+    sdf) echo "common.h tri.h pen_dev.h" ;;
     fc|loop) echo "common.h fc_dev.h" ;;
     *) echo "common.h" ;;
   esac
 }
-for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep loop; do
+for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep stage loop; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done

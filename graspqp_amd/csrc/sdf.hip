@@ -228,42 +228,16 @@ __global__ void gq_sdf_bwd_kernel(const float* __restrict__ g, const float* __re
   grad_points[i] = 2.0f * (points[i] - closest[i]) * g[i / 3];
 }
 
-// ---- hand penetration: max over links of the signed distance (inside positive) of object surface points ----------
-// link_T: (B, L, 12) row-major [R | t] of each mesh link in the hand frame; Rg (B,9) global rotation; hand_pose (B,D)
-// holds the global translation in its first three entries.  Outputs per (row, point): dis, argmax link, and
-// gvec = d dis / d x_h (hand frame).
-struct GqPenArgs {
-  const float* surf;  // (n_obj, P, 3)
-  const float* hand_pose;
-  const float* Rg;
-  const float* link_T;
-  const GqFace* rec;
-  const int32_t* off;  // (L+1)
-  const float* aabb;   // (L,8) lo.xyz,-,hi.xyz,-
-  const float* sub_aabb;   // (n_sub,8) boxes of the 16-face sub-clusters (faces Morton-sorted per link)
-  const int32_t* sub_off;  // (L+1)
-  const float* occ_invz;   // (L) 32 / z-extent of the link AABB (x, y scales ride in the pads of aabb)
-  const uint32_t* occ;     // (L, 32*32) words: bit ix of word iz*32+iy set <=> voxel may contain interior/surface
-  const uint32_t* cand_off;  // (L*32768 + 1) candidate-list offsets per voxel, or null (gq_cand_fill_kernel)
-  const uint16_t* cand_idx;  // face indices (local to the link mesh) that can be closest to some point of the voxel
-  int B, P, L, D, batch_each;
-  float* dis;     // (B, P)
-  int32_t* link;  // (B, P)
-  float* gvec;    // (B, P, 3)
-  uint64_t* span;  // optional [min start, max end] of the launch in 100 MHz s_memrealtime ticks
-  unsigned long long* dbg;  // optional counters: [0] needing (point,link) pairs, [1] (wave,link) evaluations,
-                            // [2] (wave,sub-cluster) evaluations, [3] waves
-};
+#include "pen_dev.h"
 
-// launch time span in 100 MHz s_memrealtime ticks, sharded 64 ways so the atomics of 1e3 blocks do not pile up on one
-// address: span[2*s] = min start, span[2*s+1] = max end of the blocks with (linear block id % 64) == s
-__device__ __forceinline__ void gq_span_open(uint64_t* span) {
-  const unsigned s = (blockIdx.x + blockIdx.y * gridDim.x) & 63u;
-  atomicMin((unsigned long long*)&span[2 * s], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+template <bool EVAL>
+__global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
+  extern __shared__ char gq_lds[];
+  gq_pen_grid_body<EVAL>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
 }
-__device__ __forceinline__ void gq_span_close(uint64_t* span) {
-  const unsigned s = (blockIdx.x + blockIdx.y * gridDim.x) & 63u;
-  atomicMax((unsigned long long*)&span[2 * s + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+__global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
+  extern __shared__ char gq_lds[];
+  gq_pen_bwd_body(g, (int)blockIdx.x, gq_lds);
 }
 
 // MODE 0 ("exact"): dis is the exact max over links for every point.  A link is skipped for a whole wavefront
@@ -276,7 +250,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
   const int row = blockIdx.y;
   const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g.span && threadIdx.x == 0) gq_span_open(g.span);
+  if (g.span && threadIdx.x == 0) gq_span_open(g.span, blockIdx.x + blockIdx.y * gridDim.x);
   const bool ok = pt < g.P;
   const int obj = row / g.batch_each;
   const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
@@ -366,7 +340,7 @@ __global__ __launch_bounds__(256) void gq_hand_pen_kernel(GqPenArgs g) {
   }
   if (g.span) {  // last store of the block is done: close the launch's time span
     __syncthreads();
-    if (threadIdx.x == 0) gq_span_close(g.span);
+    if (threadIdx.x == 0) gq_span_close(g.span, blockIdx.x + blockIdx.y * gridDim.x);
   }
 }
 
@@ -394,7 +368,7 @@ __global__ __launch_bounds__(256) void gq_pen_scan_kernel(GqPenArgs g, GqPenQ q)
   extern __shared__ float s_link[];  // L x 24: link transform (12) + padded AABB (8) + occupancy z scale (1) + pad
   const int row = blockIdx.y;
   const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g.span && threadIdx.x == 0) gq_span_open(g.span);
+  if (g.span && threadIdx.x == 0) gq_span_open(g.span, blockIdx.x + blockIdx.y * gridDim.x);
   for (int i = threadIdx.x; i < g.L * 24; i += blockDim.x) {
     const int l = i / 24, k = i % 24;
     float v = 0.0f;
@@ -562,367 +536,7 @@ __global__ __launch_bounds__(256) void gq_pen_finalize_kernel(GqPenArgs g, GqPen
   }
   if (g.span) {
     __syncthreads();
-    if (threadIdx.x == 0) gq_span_close(g.span);
-  }
-}
-
-// Backward of the hand-penetration query for an upstream gradient w (B,P) on `dis`:
-//   link wrench (hand frame, about the hand origin): f_l -= w G, m_l -= w x_h x G     (G = gvec)
-//   gRt[0..2]  = sum w G   (so that grad_t = -R gsum)
-//   gRt[3..11] = sum w x_h (x) G  (row-major K, so that grad_R = R K)
-// One block per row; contributions are folded in a fixed order (lane order within a wave, wave order within the
-// block) so the result is bitwise reproducible.
-struct GqPenBwdArgs {
-  const float* surf;
-  const float* hand_pose;
-  const float* Rg;
-  const float* w;
-  const int32_t* link;
-  const float* gvec;
-  int B, P, L, D, batch_each;
-  float* wrench;  // (B, L, 6)
-  float* gRt;     // (B, 12)
-  const float* dis;  // when w == nullptr: w = w_pen * [dis > 0]  (energy.py:59-61), and e_pen[row] = sum relu(dis)
-  float w_pen;
-  float* e_pen;
-  uint64_t* span;      // optional: the forward query's 64 x {min start, max end} shards ...
-  uint64_t* span_acc;  // ... folded into {sum of spans, launches} and re-armed here (the query is over by now)
-};
-
-// One block per row, surface points in super-chunks of 4096.  Phase A: every thread reads the weights of its 16 points
-// (loads in flight together), the contributing ones (w != 0) are compacted IN POINT ORDER into an LDS list of
-// (link, w*G, x_h) records (ballot prefix inside a wave, (slice, wave) counts across the block) -- the order is
-// independent of scheduling.  Phase B: thread a < L*6 + 12 owns one accumulator and folds the list in order.
-#define GQ_PENB_K 16
-#define GQ_PENB_LIST 4096
-__global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
-  __shared__ float s_rec[GQ_PENB_LIST * 6];
-  __shared__ unsigned char s_lnk[GQ_PENB_LIST];
-  __shared__ int s_cnt[GQ_PENB_K * 4];
-  const int row = blockIdx.x;
-  const int tid = threadIdx.x, lane = gq_lane(), wv = tid / GQ_WAVE;
-  const int obj = row / g.batch_each;
-  const float* hp = g.hand_pose + (size_t)row * g.D;
-  const float* R = g.Rg + (size_t)row * 9;
-  if (g.span && row == 0 && wv == 0) {
-    unsigned long long t0 = g.span[2 * lane], t1 = g.span[2 * lane + 1];
-    if (t1 == 0ull) t0 = ~0ull;  // shard saw no block
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned long long a0 = __shfl_xor(t0, o, GQ_WAVE), a1 = __shfl_xor(t1, o, GQ_WAVE);
-      t0 = a0 < t0 ? a0 : t0;
-      t1 = a1 > t1 ? a1 : t1;
-    }
-    g.span[2 * lane] = ~0ull;
-    g.span[2 * lane + 1] = 0ull;
-    if (lane == 0 && t1 > t0) {
-      g.span_acc[0] += t1 - t0;
-      g.span_acc[1] += 1ull;
-    }
-  }
-  float e_acc = 0.0f;
-  for (int base = 0; base < g.P; base += GQ_PENB_K * 256) {
-    float w[GQ_PENB_K];
-#pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
-      const int pt = base + k * 256 + tid;
-      if (g.w) {
-        w[k] = (pt < g.P) ? g.w[(size_t)row * g.P + pt] : 0.0f;
-      } else {
-        const float d = (pt < g.P) ? g.dis[(size_t)row * g.P + pt] : 0.0f;
-        w[k] = d > 0.0f ? g.w_pen : 0.0f;
-        e_acc += d > 0.0f ? d : 0.0f;
-      }
-    }
-    unsigned long long m[GQ_PENB_K];
-#pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
-      m[k] = __ballot(w[k] != 0.0f);
-      if (lane == 0) s_cnt[k * 4 + wv] = __popcll(m[k]);
-    }
-    __syncthreads();
-    int run = 0;  // entries before slice k, wave wv
-#pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
-      int off = run;
-      for (int q = 0; q < wv; ++q) off += s_cnt[k * 4 + q];
-      run += s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
-      if (w[k] != 0.0f) {
-        const int pt = base + k * 256 + tid;
-        const size_t o = (size_t)row * g.P + pt;
-        const int i = off + __popcll(m[k] & ((1ull << lane) - 1ull));
-        const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
-        const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
-        s_rec[i * 6 + 0] = w[k] * g.gvec[o * 3];
-        s_rec[i * 6 + 1] = w[k] * g.gvec[o * 3 + 1];
-        s_rec[i * 6 + 2] = w[k] * g.gvec[o * 3 + 2];
-        s_rec[i * 6 + 3] = xh.x;
-        s_rec[i * 6 + 4] = xh.y;
-        s_rec[i * 6 + 5] = xh.z;
-        s_lnk[i] = (unsigned char)g.link[o];
-      }
-    }
-    __syncthreads();
-    const int n = run;  // block-uniform
-    // fold, wave-parallel and in a fixed order: a wavefront takes a group of 4 links (24 accumulators) or the group of
-    // the 12 global sums; lane j adds entries j, j+64, ... into registers, then the fixed DPP tree adds the lanes.
-    //   wrench f_l -= G, m_l -= x_h x G ; gsum += G ; K += x_h (x) G      (G = r[0..2], x_h = r[3..5])
-    const int n_lgroups = (g.L + 3) / 4;
-    for (int grp = wv; grp <= n_lgroups; grp += 4) {  // wave-uniform
-      float part[24];
-#pragma unroll
-      for (int q = 0; q < 24; ++q) part[q] = 0.0f;
-      const int l0 = grp * 4;
-      for (int i = lane; i < n; i += GQ_WAVE) {
-        const float* r = s_rec + i * 6;
-        const gq3 G = gq_mk(r[0], r[1], r[2]), x = gq_mk(r[3], r[4], r[5]);
-        if (grp < n_lgroups) {
-          const gq3 mm = gq_cross(x, G);
-          const int dl = (int)s_lnk[i] - l0;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float sel = (dl == q4) ? 1.0f : 0.0f;
-            part[q4 * 6 + 0] -= sel * G.x;
-            part[q4 * 6 + 1] -= sel * G.y;
-            part[q4 * 6 + 2] -= sel * G.z;
-            part[q4 * 6 + 3] -= sel * mm.x;
-            part[q4 * 6 + 4] -= sel * mm.y;
-            part[q4 * 6 + 5] -= sel * mm.z;
-          }
-        } else {
-          part[0] += G.x; part[1] += G.y; part[2] += G.z;
-          part[3] += x.x * G.x; part[4] += x.x * G.y; part[5] += x.x * G.z;
-          part[6] += x.y * G.x; part[7] += x.y * G.y; part[8] += x.y * G.z;
-          part[9] += x.z * G.x; part[10] += x.z * G.y; part[11] += x.z * G.z;
-        }
-      }
-      const int nq = (grp < n_lgroups) ? 24 : 12;
-#pragma unroll
-      for (int q = 0; q < 24; ++q) {
-        if (q < nq) {
-          const float tot = gq_dpp_sum(part[q]);
-          if (lane == 0) {
-            if (grp < n_lgroups) {
-              const int l = l0 + q / 6;
-              if (l < g.L) {
-                float* dst = g.wrench + ((size_t)row * g.L + l) * 6 + (q % 6);
-                *dst = (base == 0 ? 0.0f : *dst) + tot;
-              }
-            } else {
-              float* dst = g.gRt + (size_t)row * 12 + q;
-              *dst = (base == 0 ? 0.0f : *dst) + tot;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (g.e_pen) {  // fixed order: thread-local (k ascending), DPP tree per wave, waves 0..3
-    const float ws = gq_dpp_sum(e_acc);
-    if (lane == 0) s_rec[wv] = ws;
-    __syncthreads();
-    if (tid == 0) g.e_pen[row] = ((s_rec[0] + s_rec[1]) + s_rec[2]) + s_rec[3];
-  }
-}
-
-// ---- penetration-only query with per-voxel candidate faces (the hot path of E_pen) -------------------------------
-// One block = 256 surface points of one row, no global queues, no global atomics.
-//   A  every thread walks the links for its point: bounding sphere of the link box (LDS), link frame, AABB, occupancy
-//      bit of the 32^3 voxel.  Only 2e3 .. 3e4 of the 9e6 (point, link) pairs of a config-2 launch survive; a survivor
-//      becomes an ENTRY in LDS and its voxel's candidate faces become ITEMS (entry, j) in LDS.
-//   B  the block's threads share the items evenly: one (point, face) ranking each, all lanes busy, independent gathers
-//      in flight; the minimum per entry is taken with a 64-bit LDS atomicMin on (distance, original face index, face),
-//      which is independent of the processing order.
-//   C  one thread per entry finishes the winner exactly (closest point, sign); penetrating entries compete per point
-//      with a 64-bit LDS atomicMax on (dis, 255 - link, entry) -- the max over links with torch's first-index tie rule.
-//   D  the point's own thread writes dis (every point) and link / gradient (penetrating points only).
-// The candidate list of a voxel holds every face that is closest for SOME point of the voxel (gq_cand_kernel), so the
-// result equals the brute-force scan of the whole link mesh.  Entries / items beyond the LDS capacities are ranked
-// inline by the thread that found them (same arithmetic, just slower).
-#define GQ_PG_ECAP 512
-#define GQ_PG_ICAP 4096
-struct GqPgEntry {
-  float x, y, z;      // point in the link frame
-  uint32_t c0;        // first candidate
-  uint16_t pt, link;  // local point index, link
-};
-__device__ __forceinline__ unsigned long long gq_rank_key(float d2, unsigned orig_local, unsigned f_local) {
-  unsigned b = __float_as_uint(d2);
-  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving map of floats onto unsigned
-  return ((unsigned long long)b << 32) | ((unsigned long long)(orig_local & 0xffffu) << 16) | (f_local & 0xffffu);
-}
-template <bool EVAL>
-__global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
-  extern __shared__ float s_link[];  // L x 24: link transform (12) + padded AABB (8) + occupancy z scale (1) + pad,
-                                     // then L x 4: bounding sphere of the link box in the hand frame (centre, r^2)
-  __shared__ GqPgEntry s_ent[GQ_PG_ECAP];
-  __shared__ unsigned long long s_ekey[GQ_PG_ECAP];
-  __shared__ float s_ecl[GQ_PG_ECAP * 4];  // closest point (link frame) + dis of the finished entries
-  __shared__ uint32_t s_item[GQ_PG_ICAP];  // entry << 16 | j
-  __shared__ unsigned long long s_pkey[256];
-  __shared__ int s_cnt[2];
-  float* s_sph = s_link + g.L * 24;
-  const int row = blockIdx.y, tid = threadIdx.x;
-  const int pt = blockIdx.x * blockDim.x + tid;
-  if (g.span && tid == 0) gq_span_open(g.span);
-  for (int i = tid; i < g.L * 24; i += blockDim.x) {
-    const int l = i / 24, k = i % 24;
-    float v = 0.0f;
-    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
-    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
-    else if (k == 20) v = g.occ_invz[l];
-    s_link[i] = v;
-  }
-  if (tid < g.L) {
-    const int l = tid;
-    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
-    const float* bb = g.aabb + l * 8;
-    const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
-    const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
-    s_sph[l * 4 + 0] = T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3];
-    s_sph[l * 4 + 1] = T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7];
-    s_sph[l * 4 + 2] = T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11];
-    s_sph[l * 4 + 3] = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
-  }
-  if (tid < 2) s_cnt[tid] = 0;
-  s_pkey[tid] = 0ull;
-  const bool ok = pt < g.P;
-  const int obj = row / g.batch_each;
-  const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
-  const float* hp = g.hand_pose + (size_t)row * g.D;
-  const float* R = g.Rg + (size_t)row * 9;
-  const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
-  __syncthreads();
-  // ---- A: scan -------------------------------------------------------------------------------------------------
-  float in_dis = 0.0f;  // result of entries this thread had to rank inline (capacity overflow)
-  int in_link = -1;
-  gq3 in_cl = gq_mk(0, 0, 0), in_xl = gq_mk(0, 0, 0);
-  for (int l = 0; l < g.L; ++l) {
-    // bounding sphere first (one LDS read, 7 VALU ops); the surface points are Morton-ordered, so a wavefront is a
-    // compact patch of the object and most (wavefront, link) pairs end here
-    const float4 sph = *reinterpret_cast<const float4*>(s_sph + l * 4);
-    const gq3 dc = xh - gq_mk(sph.x, sph.y, sph.z);
-    const bool near = ok && gq_dot(dc, dc) <= sph.w;
-    if (__ballot(near) == 0ull) continue;
-    const float* T = s_link + l * 24;
-    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
-    const float* bb = T + 12;
-    if (!(near && gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
-    const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
-    const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
-    if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
-    if (!EVAL) continue;
-    const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
-    const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
-    if (len == 0u) continue;
-    const int e = atomicAdd(&s_cnt[0], 1);
-    int ib = GQ_PG_ICAP;
-    if (e < GQ_PG_ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
-    if (e < GQ_PG_ECAP && ib + (int)len <= GQ_PG_ICAP) {
-      GqPgEntry en;
-      en.x = xl.x; en.y = xl.y; en.z = xl.z;
-      en.c0 = c0;
-      en.pt = (uint16_t)tid;
-      en.link = (uint16_t)l;
-      s_ent[e] = en;
-      s_ekey[e] = ~0ull;
-      for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
-    } else {  // no room: rank the candidates here
-      if (e < GQ_PG_ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
-      const int f0 = g.off[l];
-      float bd = GQ_INF_F;
-      unsigned bo = 0xffffffffu;
-      int bi = -1;
-      for (uint32_t c = c0; c < c0 + len; ++c) {
-        const int f = f0 + (int)g.cand_idx[c];
-        const GqFace fc = g.rec[f];
-        const float d2 = gq_tri_rank(fc, xl - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
-        const unsigned orig = (unsigned)__float_as_int(fc.r5.z);
-        if (d2 < bd || (d2 == bd && orig < bo)) {
-          bd = d2;
-          bo = orig;
-          bi = f;
-        }
-      }
-      const GqSdfOut o = gq_tri_finish(g.rec[bi], xl);
-      const float dis = sqrtf(o.dist2 + 1e-8f);
-      if (o.sign < 0 && dis > in_dis) {
-        in_dis = dis;
-        in_link = l;
-        in_cl = o.closest;
-        in_xl = xl;
-      }
-    }
-  }
-  __syncthreads();
-  const int n_ent = min(s_cnt[0], GQ_PG_ECAP), n_item = min(s_cnt[1], GQ_PG_ICAP);
-  // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
-  for (int i = tid; i < n_item; i += 256) {
-    const uint32_t it = s_item[i];
-    const int e = (int)(it >> 16);
-    const GqPgEntry en = s_ent[e];
-    const int f0 = g.off[en.link];
-    const unsigned fl = g.cand_idx[en.c0 + (it & 0xffffu)];
-    const GqFace fc = g.rec[f0 + (int)fl];
-    const float d2 = gq_tri_rank(fc, gq_mk(en.x - fc.r0.x, en.y - fc.r0.y, en.z - fc.r0.z));
-    const unsigned orig = (unsigned)__float_as_int(fc.r5.z) - (unsigned)f0;  // original index inside the mesh
-    atomicMin(&s_ekey[e], gq_rank_key(d2, orig, fl));
-  }
-  __syncthreads();
-  // ---- C: finish the winner of every entry ----------------------------------------------------------------------
-  for (int e = tid; e < n_ent; e += 256) {
-    const GqPgEntry en = s_ent[e];
-    if (en.c0 == 0xffffffffu) continue;  // was ranked inline
-    const int f = g.off[en.link] + (int)(s_ekey[e] & 0xffffull);
-    const gq3 xl = gq_mk(en.x, en.y, en.z);
-    const GqSdfOut o = gq_tri_finish(g.rec[f], xl);
-    if (o.sign < 0) {  // inside the link: dis = +sqrt(d^2 + 1e-8) > 0
-      const float dis = sqrtf(o.dist2 + 1e-8f);
-      s_ecl[e * 4 + 0] = o.closest.x;
-      s_ecl[e * 4 + 1] = o.closest.y;
-      s_ecl[e * 4 + 2] = o.closest.z;
-      s_ecl[e * 4 + 3] = dis;
-      atomicMax(&s_pkey[en.pt], ((unsigned long long)__float_as_uint(dis) << 32) |
-                                    ((unsigned long long)(255 - (int)en.link) << 16) | (unsigned long long)e);
-    }
-  }
-  __syncthreads();
-  // ---- D: outputs ---------------------------------------------------------------------------------------------------
-  if (ok) {
-    // dis for every point (coalesced 4 B); link and gradient only where a link is penetrated -- nothing downstream
-    // reads them elsewhere (energy.py:59-61 zeroes dis <= 0), the caller provides zero-initialised buffers
-    float best_dis = in_dis;
-    int best_link = in_link;
-    gq3 best_cl = in_cl, best_xl = in_xl;
-    const unsigned long long pk = s_pkey[tid];
-    if (pk != 0ull) {
-      const int e = (int)(pk & 0xffffull);
-      const float dis = s_ecl[e * 4 + 3];
-      const int l = (int)s_ent[e].link;
-      if (dis > best_dis || (dis == best_dis && l < best_link)) {
-        best_dis = dis;
-        best_link = l;
-        best_cl = gq_mk(s_ecl[e * 4], s_ecl[e * 4 + 1], s_ecl[e * 4 + 2]);
-        best_xl = gq_mk(s_ent[e].x, s_ent[e].y, s_ent[e].z);
-      }
-    }
-    const size_t o = (size_t)row * g.P + pt;
-    g.dis[o] = best_link >= 0 ? best_dis : -1e30f;
-    if (best_link >= 0) {
-      const float* T = s_link + best_link * 24;
-      const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-      const gq3 gh = gq_mv(Rl, (1.0f / best_dis) * (best_xl - best_cl));
-      g.link[o] = best_link;
-      g.gvec[o * 3 + 0] = gh.x;
-      g.gvec[o * 3 + 1] = gh.y;
-      g.gvec[o * 3 + 2] = gh.z;
-    }
-  }
-  if (g.span) {
-    __syncthreads();
-    if (tid == 0) gq_span_close(g.span);
+    if (threadIdx.x == 0) gq_span_close(g.span, blockIdx.x + blockIdx.y * gridDim.x);
   }
 }
 
@@ -1021,25 +635,6 @@ __global__ __launch_bounds__(256) void gq_occ_centres_kernel(const GqFace* __res
     if (o.sign < 0) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], 1u << ix);
   }
 }
-
-// ---- mesh-set handle: concatenated face records of n_mesh meshes on the device -----------------------------------
-struct gqMeshSet {
-  GqFace* rec;         // records, faces Morton-sorted inside each mesh
-  int32_t* off_dev;    // (n_mesh+1) face offsets
-  int32_t* off_host;
-  float* aabb_dev;     // (n_mesh, 8) box of each mesh in its own frame
-  float* sub_aabb_dev; // (n_sub, 8) boxes of 16-face sub-clusters
-  int32_t* sub_off_dev;   // (n_mesh+1)
-  float* cl_aabb_dev;  // (n_cl, 16) oriented boxes of the 64-face clusters (gq_cluster_bound)
-  int32_t* cl_off_dev;    // (n_mesh+1)
-  uint32_t* occ_dev;   // (n_mesh, 1024) occupancy bits or null (gq_meshset_build_occupancy)
-  float* occ_invz_dev; // (n_mesh)
-  uint32_t* cand_off_dev;  // (n_mesh*32768 + 1) per-voxel candidate lists or null (gq_meshset_build_occupancy)
-  uint16_t* cand_idx_dev;
-  int64_t n_cand;
-  int n_mesh;
-  int64_t n_faces;
-};
 
 #include <algorithm>
 #include <cmath>
@@ -1411,33 +1006,11 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
                         int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
                         int penetration_only, float* dis, int32_t* link, float* gvec, void* workspace,
                         size_t workspace_bytes, void* timer, uint64_t* span, void* stream) {
-  GQ_REQUIRE(links && surface_points && hand_pose && Rg && link_T && dis && link && gvec, "hand_pen_forward: null");
-  GQ_REQUIRE(n_obj > 0 && n_surface > 0 && batch_each > 0 && pose_dim >= 9, "hand_pen_forward: bad sizes");
   GqPenArgs a{};
-  a.surf = surface_points;
-  a.hand_pose = hand_pose;
-  a.Rg = Rg;
-  a.link_T = link_T;
-  a.rec = links->rec;
-  a.off = links->off_dev;
-  a.aabb = links->aabb_dev;
-  a.sub_aabb = links->sub_aabb_dev;
-  a.sub_off = links->sub_off_dev;
-  a.occ = links->occ_dev;
-  a.occ_invz = links->occ_invz_dev;
-  a.cand_off = links->cand_off_dev;
-  a.cand_idx = links->cand_idx_dev;
-  a.B = (int)(n_obj * batch_each);
-  a.P = (int)n_surface;
-  a.L = links->n_mesh;
-  a.D = pose_dim;
-  a.batch_each = (int)batch_each;
-  a.dis = dis;
-  a.link = link;
-  a.gvec = gvec;
-  a.span = span;
+  int rc0 = gq_pen_fill(links, surface_points, n_obj, n_surface, batch_each, hand_pose, pose_dim, Rg, link_T, dis, link,
+                        gvec, span, &a);
+  if (rc0) return rc0;
   a.dbg = gq_pen_dbg_;
-  GQ_REQUIRE(a.B <= 65535, "hand_pen_forward: B=%d exceeds grid.y limit", a.B);
   const dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)a.B);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timer) {  // gqTimer: the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), not stream markers
@@ -1446,11 +1019,11 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   }
   if (penetration_only == 1 && a.occ && a.cand_off) {
     // one pass over the (point, link) pairs, candidate faces from the voxel grid (see gq_pen_grid_kernel)
-    hipExtLaunchKernelGGL(gq_pen_grid_kernel<true>, grid, dim3(256), (size_t)a.L * 28 * sizeof(float),
-                          (hipStream_t)stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(gq_pen_grid_kernel<true>, grid, dim3(256), gq_pen_grid_lds_bytes(a.L), (hipStream_t)stream, e0,
+                          e1, 0, a);
   } else if (penetration_only == 9 && a.occ && a.cand_off) {  // diagnostics: the scan without candidate evaluation
-    hipExtLaunchKernelGGL(gq_pen_grid_kernel<false>, grid, dim3(256), (size_t)a.L * 28 * sizeof(float),
-                          (hipStream_t)stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(gq_pen_grid_kernel<false>, grid, dim3(256), gq_pen_grid_lds_bytes(a.L), (hipStream_t)stream,
+                          e0, e1, 0, a);
   } else if ((penetration_only == 1 || penetration_only == 3) && workspace != nullptr) {
     // queue-based, load-balanced path without candidate lists (see gq_pen_scan_kernel); 3 forces it for A/B tests
     const size_t cap_link = (size_t)a.B * a.P;
@@ -1491,30 +1064,12 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
                          int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                          const float* grad_dis, const int32_t* link, const float* gvec, float* link_wrench, float* gRt,
                          const float* dis, float w_pen, float* e_pen, uint64_t* span, uint64_t* span_acc, void* stream) {
-  GQ_REQUIRE(surface_points && hand_pose && Rg && link && gvec && link_wrench && gRt, "hand_pen_backward: null");
-  GQ_REQUIRE(grad_dis || (dis && e_pen), "hand_pen_backward: need grad_dis, or dis + e_pen for the fused E_pen form");
-  GQ_REQUIRE(!span || span_acc, "hand_pen_backward: span without span_acc");
-  GQ_REQUIRE(n_links > 0 && n_links <= 160 && n_obj > 0 && n_surface > 0 && batch_each > 0, "hand_pen_backward: sizes");
   GqPenBwdArgs a{};
-  a.surf = surface_points;
-  a.hand_pose = hand_pose;
-  a.Rg = Rg;
-  a.w = grad_dis;
-  a.link = link;
-  a.gvec = gvec;
-  a.B = (int)(n_obj * batch_each);
-  a.P = (int)n_surface;
-  a.L = n_links;
-  a.D = pose_dim;
-  a.batch_each = (int)batch_each;
-  a.wrench = link_wrench;
-  a.gRt = gRt;
-  a.dis = dis;
-  a.w_pen = w_pen;
-  a.e_pen = grad_dis ? nullptr : e_pen;
-  a.span = span;
-  a.span_acc = span_acc;
-  hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
+  int rc0 = gq_pen_bwd_fill(n_links, surface_points, n_obj, n_surface, batch_each, hand_pose, pose_dim, Rg, grad_dis, link,
+                            gvec, link_wrench, gRt, dis, w_pen, e_pen, span, span_acc, &a);
+  if (rc0) return rc0;
+  hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), gq_pen_bwd_lds_bytes(), (hipStream_t)stream,
+                     a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -1,0 +1,92 @@
+// Two "stage" kernels that run the force-closure branch and the hand-penetration branch of one MALA* iteration side by
+// side in the SAME launch (the branches are independent until the FK backward, scripts/fit.py:434-438):
+//
+//   stage A   blocks [0, B)        fc head   contact terms + cone matrix + all QP iterations of row b   (wave 0 only)
+//             blocks [B, B + gx B) pen query penetration-only hand query of 256 surface points of one row
+//   stage B   blocks [0, B)        fc tail   stop rule + E_fc + QP backward + contact gradient          (wave 0 only)
+//             blocks [B, 2B)       pen bwd   link wrenches + E_pen of one row
+//
+// With B = 256 rows neither branch fills 256 CUs on its own (the QP is one wavefront per row), and separate streams
+// cost 20..100 us of cross-queue dependency latency per iteration on this platform; putting both roles in one grid gives
+// the overlap without any inter-queue hand-shake.  The bodies are the ones of fcstep.hip / sdf.hip (same arithmetic),
+// the long-running fc blocks come first so that they are resident from the start.
+#include "fcstep_dev.h"
+#include "pen_dev.h"
+
+int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
+                       float* runmin, int* kstar, int32_t* n_iter, void* stream);
+
+template <int NC>
+__global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx) {
+  extern __shared__ char gq_lds[];
+  const int b = (int)blockIdx.x;
+  if (b < f.B) {
+    if (threadIdx.x >= GQ_WAVE) return;
+    gq_fc_head_body<NC>(f, b, reinterpret_cast<float*>(gq_lds));
+  } else {
+    const int q = b - f.B;
+    gq_pen_grid_body<true>(p, q % gx, q / gx, gq_lds);
+  }
+}
+
+template <int NC, int RPL>
+__global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBwdArgs p) {
+  extern __shared__ char gq_lds[];
+  const int b = (int)blockIdx.x;
+  if (b < f.B) {
+    if (threadIdx.x >= GQ_WAVE) return;
+    gq_fc_tail_body<NC, RPL>(f, b, reinterpret_cast<float*>(gq_lds));
+  } else {
+    gq_pen_bwd_body(p, b - f.B, gq_lds);
+  }
+}
+
+extern "C" {
+
+int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream) {
+  GQ_REQUIRE(fc && pen, "fc_pen_step: null descriptor");
+  hipStream_t st = (hipStream_t)stream;
+  GqFcStepArgs f{};
+  float* runmin = nullptr;
+  int rc = gq_fc_step_fill(fc->dist_sq, fc->sign, fc->obj_dir, fc->closest, fc->contact_pts, fc->hand_normals, fc->cog,
+                           fc->batch, fc->n_contact, fc->n_cone, fc->friction, fc->torque_weight, fc->max_limit,
+                           fc->svd_gain, fc->values_gain, fc->eps, fc->max_iter, fc->w_dis, fc->w_fc, fc->obj_normal,
+                           fc->g_contact_pts, fc->g_hand_normals, fc->e_fc, fc->x_sum, fc->n_iter, fc->workspace,
+                           fc->workspace_bytes, &f, &runmin);
+  if (rc) return rc;
+  GqPenArgs p{};
+  rc = gq_pen_fill(pen->links, pen->surface_points, pen->n_obj, pen->n_surface, pen->batch_each, pen->hand_pose,
+                   pen->pose_dim, pen->Rg, pen->link_T, pen->dis, pen->link, pen->gvec, pen->span, &p);
+  if (rc) return rc;
+  GQ_REQUIRE(p.occ && p.cand_off, "fc_pen_step: the link mesh set has no voxel candidate lists (gq_meshset_build_occupancy)");
+  GQ_REQUIRE(p.B == f.B, "fc_pen_step: the two descriptors disagree on the batch (%d vs %d)", p.B, f.B);
+  GqPenBwdArgs pb{};
+  rc = gq_pen_bwd_fill(p.L, pen->surface_points, pen->n_obj, pen->n_surface, pen->batch_each, pen->hand_pose, pen->pose_dim,
+                       pen->Rg, nullptr, pen->link, pen->gvec, pen->link_wrench, pen->gRt, pen->dis, pen->w_pen, pen->e_pen,
+                       pen->span, pen->span_acc, &pb);
+  if (rc) return rc;
+  const int gx = (p.P + 255) / 256;
+  const bool two = f.nz > GQ_WAVE;
+  const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)f.n * 6 * sizeof(float));
+  const size_t lds_b = std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float));
+  const dim3 grid_a((unsigned)(f.B + gx * p.B)), grid_b((unsigned)(2 * f.B)), block(256);
+  if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx);
+  else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx);
+  GQ_LAUNCH_CHECK();
+  const bool fused_stop = f.B <= 4 * GQ_WAVE && f.max_iter <= 16;
+  if (!fused_stop) {
+    rc = gq_qp_stop_launch_(f.resid, f.mu_tab, f.B, f.max_iter, f.eps, f.not_improved_lim, runmin, f.kstar, f.n_iter, stream);
+    if (rc) return rc;
+  }
+  if (two) {
+    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<2, 4>), grid_b, block, lds_b, st, f, pb);
+    else hipLaunchKernelGGL((gq_stage_b_kernel<2, 0>), grid_b, block, lds_b, st, f, pb);
+  } else {
+    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<1, 4>), grid_b, block, lds_b, st, f, pb);
+    else hipLaunchKernelGGL((gq_stage_b_kernel<1, 0>), grid_b, block, lds_b, st, f, pb);
+  }
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+}  // extern "C"

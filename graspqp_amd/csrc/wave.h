@@ -81,3 +81,11 @@ __device__ __forceinline__ void gq_wave_sums_d(double (&v)[K]) {
     v[k] = gq_join_d(__builtin_amdgcn_readlane(s.lo, src_lane), __builtin_amdgcn_readlane(s.hi, src_lane));
   }
 }
+
+// LDS hand-over between the lanes of ONE wavefront (blocks whose other wavefronts have exited, or single-wave blocks):
+// LDS operations of a wavefront execute in order, so only the compiler has to be kept from moving them.
+__device__ __forceinline__ void gq_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

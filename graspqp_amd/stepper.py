@@ -106,6 +106,27 @@ class GraspStepper:
         e.w_dis, e.w_fc, e.w_pen, e.w_spen, e.w_joints = (float(self.w[k]) for k in TERM_NAMES)
         e.e_dis, e.e_joints, e.total = self.terms_new[0].data_ptr(), self.terms_new[4].data_ptr(), self.total_new.data_ptr()
         self._row_energy = e
+        # descriptors of the fused force-closure + penetration launches (gq_fc_pen_step)
+        fc, fd = self.fc, _C.FcStepDesc()
+        fd.dist_sq, fd.sign, fd.obj_dir, fd.closest = (t.data_ptr() for t in (self.d2, self.sgn, self.onrm, self.closest))
+        fd.contact_pts, fd.hand_normals, fd.cog = self.cpts.data_ptr(), self.cnrm.data_ptr(), self.cog.data_ptr()
+        fd.batch, fd.n_contact, fd.n_cone = B, n, int(fc["n_cone_vecs"])
+        fd.friction, fd.torque_weight, fd.max_limit = float(fc["friction"]), float(fc["torque_weight"]), float(fc["max_limit"])
+        fd.svd_gain, fd.values_gain, fd.eps, fd.max_iter = (float(fc["svd_gain"]), float(fc["values_gain"]), float(fc["eps"]),
+                                                            int(fc["max_iter"]))
+        fd.w_dis, fd.w_fc = float(self.w["E_dis"]), float(self.w["E_fc"])
+        fd.obj_normal, fd.g_contact_pts, fd.g_hand_normals = (t.data_ptr() for t in (self.obj_normal, self.g_cpts, self.g_cnrm))
+        fd.e_fc, fd.x_sum, fd.n_iter = self.terms_new[1].data_ptr(), self.x_sum.data_ptr(), self.n_iter.data_ptr()
+        fd.workspace, fd.workspace_bytes = self.fc_ws.data_ptr(), self.fc_nb
+        pd = _C.PenStepDesc()
+        pd.links, pd.surface_points = self.hand.links.handle, self.surf.data_ptr()
+        pd.n_obj, pd.n_surface, pd.batch_each, pd.pose_dim = self.n_obj, P, self.be, D
+        pd.Rg, pd.link_T = self.Rg.data_ptr(), self.link_T.data_ptr()
+        pd.dis, pd.link, pd.gvec = self.pen_dis.data_ptr(), self.pen_link.data_ptr(), self.pen_gvec.data_ptr()
+        pd.link_wrench, pd.gRt, pd.w_pen, pd.e_pen = (self.wrench.data_ptr(), self.gRt.data_ptr(), float(self.w["E_pen"]),
+                                                      self.terms_new[2].data_ptr())
+        pd.span, pd.span_acc = self._span.data_ptr(), self._span_acc.data_ptr()
+        self._fc_desc, self._pen_desc = fd, pd
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
     # Four pieces: FK (+ self penetration), then two independent branches (contacts -> object SDF -> E_fc fwd+bwd |
@@ -154,9 +175,15 @@ class GraspStepper:
                 f32(self.gRt), None, None, f32(self.grad_new), ctypes.byref(self._row_energy), _C.ptr(self.fk_ws),
                 self.fk_nb, st)
 
-    def _evaluate(self, pose, idx, st, fork=False, timer=None):
+    def _evaluate(self, pose, idx, st, fork=False, timer=None, fused=False):
         self._eval_fk(pose, idx, st)
-        if not fork:
+        if fused:
+            # object SDF of the contacts, then both branches side by side in two launches
+            _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,
+                    _C.f32(self.d2), _C.i32(self.sgn), _C.f32(self.onrm), _C.f32(self.closest), st)
+            self._pen_desc.hand_pose = pose.data_ptr()
+            _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
+        elif not fork:
             self._eval_contacts(st)
             self._eval_pen(pose, st, timer)
         else:
@@ -261,7 +288,7 @@ class GraspStepper:
             self._evaluate(self.pose_new, self.idx_new, st, timer=timer)
         self._accept(st)
 
-    def capture(self, fork=True):
+    def capture(self, fork=False, fused=True):
         """Capture the energy + gradient evaluation of one iteration into a hipGraph whose three independent branches
         (contacts/object SDF/E_fc | hand penetration | self penetration) may run concurrently.  Propose and accept stay
         ordinary launches: they read the current slice of the pre-generated random numbers.  The state is saved and
@@ -269,7 +296,9 @@ class GraspStepper:
         saved = [t.clone() for t in (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema,
                                      self.step_count, self.terms, self._span_acc)]
         rng = (self.gen.get_state(), self._draw_pos)
-        if self._side is None:
+        fused = fused and self.penetration_only == 1
+        fork = fork and not fused
+        if fork and self._side is None:
             self._side = torch.cuda.Stream()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -277,13 +306,13 @@ class GraspStepper:
         with torch.cuda.stream(s):
             st = _C.stream_ptr()
             self._propose(st)
-            self._evaluate(self.pose_new, self.idx_new, st, fork=fork)
+            self._evaluate(self.pose_new, self.idx_new, st, fork=fork, fused=fused)
             self._accept(st)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._evaluate(self.pose_new, self.idx_new, _C.stream_ptr(), fork=fork)
+            self._evaluate(self.pose_new, self.idx_new, _C.stream_ptr(), fork=fork, fused=fused)
         torch.cuda.synchronize()
         for t, v in zip((self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema, self.step_count,
                          self.terms, self._span_acc), saved):

@@ -293,11 +293,11 @@ struct GqPenBwdArgs {
   uint64_t* span_acc;  // ... folded into {sum of spans, launches} and re-armed here (the query is over by now)
 };
 
-// One block per row, surface points in super-chunks of 1024.  Phase A: every thread reads the weights of its 4 points
+// One block per row, surface points in rounds of up to 4096.  Phase A: every thread reads the weights of its 16 points
 // (loads in flight together), the contributing ones (w != 0) are compacted IN POINT ORDER into an LDS list of
 // (link, w*G, x_h) records (ballot prefix inside a wave, (slice, wave) counts across the block) -- the order is
 // independent of scheduling.  Phase B: thread a < L*6 + 12 owns one accumulator and folds the list in order.
-#define GQ_PENB_K 4
+#define GQ_PENB_K 16
 #define GQ_PENB_LIST 1024
 __host__ __device__ inline size_t gq_pen_bwd_lds_bytes() {
   return (size_t)GQ_PENB_LIST * 6 * 4 + GQ_PENB_K * 4 * 4 + GQ_PENB_LIST;
@@ -328,17 +328,18 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
     }
   }
   float e_acc = 0.0f;
-  for (int base = 0; base < g.P; base += GQ_PENB_K * 256) {
-    float w[GQ_PENB_K];
+  for (int base = 0; base < g.P;) {
+    float w[GQ_PENB_K], dpos[GQ_PENB_K];
 #pragma unroll
     for (int k = 0; k < GQ_PENB_K; ++k) {
       const int pt = base + k * 256 + tid;
+      dpos[k] = 0.0f;
       if (g.w) {
         w[k] = (pt < g.P) ? g.w[(size_t)row * g.P + pt] : 0.0f;
       } else {
         const float d = (pt < g.P) ? g.dis[(size_t)row * g.P + pt] : 0.0f;
         w[k] = d > 0.0f ? g.w_pen : 0.0f;
-        e_acc += d > 0.0f ? d : 0.0f;
+        dpos[k] = d > 0.0f ? d : 0.0f;
       }
     }
     unsigned long long m[GQ_PENB_K];
@@ -348,27 +349,43 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
       if (lane == 0) s_cnt[k * 4 + wv] = __popcll(m[k]);
     }
     __syncthreads();
-    int run = 0;  // entries before slice k, wave wv
+    // as many 256-point slices as fit into the LDS list (a slice holds <= 256 entries, so at least four always do);
+    // the remaining slices are taken up again by the next round
+    int kfit = 0, run = 0;
 #pragma unroll
     for (int k = 0; k < GQ_PENB_K; ++k) {
-      int off = run;
-      for (int q = 0; q < wv; ++q) off += s_cnt[k * 4 + q];
-      run += s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
-      if (w[k] != 0.0f) {
-        const int pt = base + k * 256 + tid;
-        const size_t o = (size_t)row * g.P + pt;
-        const int i = off + __popcll(m[k] & ((1ull << lane) - 1ull));
-        const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
-        const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
-        s_rec[i * 6 + 0] = w[k] * g.gvec[o * 3];
-        s_rec[i * 6 + 1] = w[k] * g.gvec[o * 3 + 1];
-        s_rec[i * 6 + 2] = w[k] * g.gvec[o * 3 + 2];
-        s_rec[i * 6 + 3] = xh.x;
-        s_rec[i * 6 + 4] = xh.y;
-        s_rec[i * 6 + 5] = xh.z;
-        s_lnk[i] = (unsigned char)g.link[o];
+      const int tot = s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
+      if (kfit == k && run + tot <= GQ_PENB_LIST) {
+        kfit = k + 1;
+        run += tot;
       }
     }
+    run = 0;  // entries before slice k
+#pragma unroll
+    for (int k = 0; k < GQ_PENB_K; ++k) {
+      if (k < kfit) {
+        int off = run;
+        for (int q = 0; q < wv; ++q) off += s_cnt[k * 4 + q];
+        run += s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
+        e_acc += dpos[k];
+        if (w[k] != 0.0f) {
+          const int pt = base + k * 256 + tid;
+          const size_t o = (size_t)row * g.P + pt;
+          const int i = off + __popcll(m[k] & ((1ull << lane) - 1ull));
+          const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
+          const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+          s_rec[i * 6 + 0] = w[k] * g.gvec[o * 3];
+          s_rec[i * 6 + 1] = w[k] * g.gvec[o * 3 + 1];
+          s_rec[i * 6 + 2] = w[k] * g.gvec[o * 3 + 2];
+          s_rec[i * 6 + 3] = xh.x;
+          s_rec[i * 6 + 4] = xh.y;
+          s_rec[i * 6 + 5] = xh.z;
+          s_lnk[i] = (unsigned char)g.link[o];
+        }
+      }
+    }
+    const bool first = base == 0;
+    base += kfit * 256;
     __syncthreads();
     const int n = run;  // block-uniform
     // fold, wave-parallel and in a fixed order: a wavefront takes a group of 4 links (24 accumulators) or the group of
@@ -413,11 +430,11 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
               const int l = l0 + q / 6;
               if (l < g.L) {
                 float* dst = g.wrench + ((size_t)row * g.L + l) * 6 + (q % 6);
-                *dst = (base == 0 ? 0.0f : *dst) + tot;
+                *dst = (first ? 0.0f : *dst) + tot;
               }
             } else {
               float* dst = g.gRt + (size_t)row * 12 + q;
-              *dst = (base == 0 ? 0.0f : *dst) + tot;
+              *dst = (first ? 0.0f : *dst) + tot;
             }
           }
         }

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
     ap.add_argument("--hand", default="allegro")
     ap.add_argument("--fork", type=int, default=0, help="1: the two branches of the evaluation as parallel hipGraph branches (A/B)")
+    ap.add_argument("--graph_iters", type=int, default=4, help="MALA* iterations captured per hipGraph")
     ap.add_argument("--fused", type=int, default=1, help="1: force-closure and penetration branches share two launches (default)")
     ap.add_argument("--graph", type=int, default=1, help="replay the iteration from hipGraphs (1, default) or launch eagerly (0)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -128,14 +129,16 @@ def main():
             torch.cuda.synchronize()
 
     if args.graph:
-        st.capture(fork=bool(args.fork), fused=bool(args.fused))
+        st.capture(fork=bool(args.fork), fused=bool(args.fused), iters=args.graph_iters)
     for _ in range(args.warmup):
         st.step()
+    st.flush()
     sync()
     st.start_kernel_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st.step()
+    st.flush()
     t_enq = time.perf_counter() - t0  # host time to enqueue the region (must stay below dt or the host is the limit)
     sync()
     dt = time.perf_counter() - t0
@@ -184,7 +187,7 @@ def main():
             "config": {"workload": f"{args.hand}, {args.n_objects} YCB-style superquadric mesh(es) per GPU "
                                    f"({fvs[0].shape[0]} faces), batch_size={args.batch_size} each, n_contact={args.n_contact}, "
                                    f"2500 surface points, 4-edge friction cones (BASELINE configs[1])",
-                       "rows_per_gpu": B, "hip_graph": bool(args.graph), "branches": ("one grid" if args.fused else "graph branches" if args.fork else "serial") if args.graph else "eager"},
+                       "rows_per_gpu": B, "hip_graph": bool(args.graph), "iterations_per_graph": args.graph_iters if args.graph else 0, "branches": ("one grid" if args.fused else "graph branches" if args.fork else "serial") if args.graph else "eager"},
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "mean_energy": float(st.energy.mean()), "accept_rate_last": float(st.accept.float().mean()),
             "roofline": roof,
         }

@@ -95,6 +95,16 @@ PenStepDesc = _struct("PenStepDesc", [
     ("pose_dim", "i"), ("Rg", "p"), ("link_T", "p"), ("dis", "p"), ("link", "p"), ("gvec", "p"), ("link_wrench", "p"),
     ("gRt", "p"), ("w_pen", "f"), ("e_pen", "p"), ("span", "p"), ("span_acc", "p")])
 
+ProposeDesc = _struct("ProposeDesc", [
+    ("hand_pose", "p"), ("grad", "p"), ("contact_idx", "p"), ("u_switch", "p"), ("new_idx", "p"), ("ema", "p"),
+    ("step", "p"), ("step_size_out", "p"), ("g2_scratch", "p"), ("energy", "p"), ("batch_each", "l"), ("z_out", "p"), ("step_size", "f"),
+    ("stepsize_period", "i"), ("decay", "f"), ("mu", "f"), ("switch_possibility", "f"), ("clip_grad", "i"),
+    ("slot_ctr", "p"), ("slots", "i")])
+AcceptDesc = _struct("AcceptDesc", [
+    ("u_accept", "p"), ("z", "p"), ("reset_mask", "p"), ("step", "p"), ("starting_temperature", "f"), ("decay", "f"),
+    ("annealing_period", "i"), ("energy", "p"), ("pose", "p"), ("idx", "p"), ("grad", "p"), ("accept", "p"),
+    ("temperature", "p"), ("n_terms", "i"), ("terms_new", "p"), ("terms", "p"), ("slot_ctr", "p"), ("slots", "i")])
+
 _lib = None
 _protos = None
 

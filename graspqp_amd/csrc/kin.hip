@@ -5,7 +5,7 @@
 // Work shape: one thread per grasp candidate (row).  Per row the work is ~2 kflop of strictly sequential 3x3
 // products down a 16-24 joint tree, i.e. latency- not throughput-bound; the per-row scratch (node transforms,
 // node wrenches) lives in a caller-provided workspace so nothing is dynamically indexed in registers.
-#include "common.h"
+#include "loop_dev.h"
 
 struct gqHand {
   int J, L, C, S, NG, max_depth;
@@ -105,6 +105,8 @@ struct GqFkArgs {
   float* e_spen;    // (B) or null: self penetration of the spheres rides along (needs spheres)
   float* g_spheres; // (B, S, 3): spen_scale * dE_spen / d centre
   float spen_scale;
+  int has_propose;   // MalaStar.try_step runs first in the same wavefront and WRITES hand_pose / idx
+  GqProposeArgs pr;
 };
 
 // order-preserving map of floats onto unsigned (and back)
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ float sRad[256];
   const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
+  if (g.has_propose) {  // the proposal of this row, then its forward kinematics
+    gq_propose_body(g.pr, row, lane);
+    __threadfence_block();
+  }
   const float* hp = g.hand_pose + (size_t)row * g.D;
   float R[9];
   gq_rot6d(hp + 3, R);
@@ -269,6 +275,8 @@ struct GqFkBwdArgs {
   float* node_F;     // (B, J, 6) workspace
   float* grad_pose;  // (B, D)
   gqRowEnergyDesc en;  // en.total != nullptr: E_dis, E_joints (+ its gradient) and the weighted total ride along
+  int has_accept;      // MalaStar.accept_step runs last in the same wavefront (needs en.total)
+  GqAcceptArgs ac;
 };
 
 __device__ __forceinline__ void gq_add6(float* a, gq3 f, gq3 m) {
@@ -458,6 +466,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     go[3] = ga.x; go[4] = ga.y; go[5] = ga.z;
     go[6] = gb.x; go[7] = gb.y; go[8] = gb.z;
   }
+  if (g.has_accept) {  // Metropolis test on the total just written, state merge of this row
+    __threadfence_block();
+    gq_accept_body(g.ac, row, lane);
+  }
 }
 
 // ---- self penetration (hand_model.py:989-1040) ----------------------------------------------------------------------
@@ -531,6 +543,8 @@ static int gq_upload(T** dst, const T* src, size_t n) {
   GQ_CHECK_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
   return GQ_OK;
 }
+
+int gq_colsq_launch_(const float* grad, int B, int D, int clip, float* g2, void* stream);  // loop.hip
 
 extern "C" {
 
@@ -628,8 +642,8 @@ int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes) {
 
 int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                   float* Rg, float* link_T, float* contact_points, float* contact_normals, float* sphere_centers,
-                  float spen_scale, float* e_spen, float* g_sphere_centers, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+                  float spen_scale, float* e_spen, float* g_sphere_centers, const gqProposeDesc* propose,
+                  void* workspace, size_t workspace_bytes, void* stream) {
   GQ_REQUIRE(h && hand_pose && Rg && link_T && workspace, "fk_forward: null pointer");
   GQ_REQUIRE(!e_spen || (sphere_centers && g_sphere_centers && h->S > 0 && h->S <= 256),
              "fk_forward: the fused self-penetration term needs sphere_centers and g_sphere_centers");
@@ -652,6 +666,44 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
   a.e_spen = e_spen;
   a.g_spheres = g_sphere_centers;
   a.spen_scale = spen_scale;
+  if (propose) {
+    const gqProposeDesc& p = *propose;
+    GQ_REQUIRE(p.hand_pose && p.grad && p.contact_idx && p.u_switch && p.new_idx && p.ema && p.step && p.slot_ctr &&
+                   p.slots > 0 && p.stepsize_period > 0 && contact_idx && a.D <= 128,
+               "fk_forward: incomplete gqProposeDesc");
+    GQ_REQUIRE(p.g2_scratch, "fk_forward: gqProposeDesc.g2_scratch (D floats) is missing");
+    GQ_REQUIRE(!p.energy || (p.z_out && p.batch_each > 1), "fk_forward: z-score needs z_out and batch_each > 1");
+    a.has_propose = 1;
+    a.pr.hand_pose = p.hand_pose;
+    a.pr.grad = p.grad;
+    a.pr.g2 = p.g2_scratch;
+    a.pr.idx = p.contact_idx;
+    a.pr.u_switch = p.u_switch;
+    a.pr.new_idx = p.new_idx;
+    a.pr.B = (int)batch;
+    a.pr.D = a.D;
+    a.pr.n = n_contact;
+    a.pr.clip = p.clip_grad;
+    a.pr.step_size = p.step_size;
+    a.pr.decay = p.decay;
+    a.pr.mu = p.mu;
+    a.pr.switch_p = p.switch_possibility;
+    a.pr.stepsize_period = p.stepsize_period;
+    a.pr.ema = p.ema;
+    a.pr.step = p.step;
+    a.pr.pose_out = const_cast<float*>(hand_pose);
+    a.pr.idx_out = const_cast<int64_t*>(contact_idx);
+    a.pr.s_out = p.step_size_out;
+    a.pr.energy = p.energy;
+    a.pr.batch_each = (int)p.batch_each;
+    a.pr.z_out = p.z_out;
+    a.pr.slot_ctr = p.slot_ctr;
+    a.pr.slots = p.slots;
+  }
+  if (propose) {  // the RMS mean couples all rows (optimizer.py:231): its own small launch, then everything per row
+    int rc = gq_colsq_launch_(propose->grad, (int)batch, a.D, propose->clip_grad, propose->g2_scratch, stream);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
@@ -660,8 +712,8 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
 int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                    const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
                    const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
-                   const float* g_R, float* grad_pose, const gqRowEnergyDesc* energy, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+                   const float* g_R, float* grad_pose, const gqRowEnergyDesc* energy, const gqAcceptDesc* accept,
+                   void* workspace, size_t workspace_bytes, void* stream) {
   GQ_REQUIRE(h && hand_pose && Rg && link_T && grad_pose && workspace, "fk_backward: null pointer");
   if (energy) {
     const gqRowEnergyDesc& e = *energy;
@@ -691,6 +743,39 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
   a.node_F = (float*)workspace + (size_t)batch * h->J * 12;
   a.grad_pose = grad_pose;
   if (energy) a.en = *energy;
+  if (accept) {
+    const gqAcceptDesc& c = *accept;
+    GQ_REQUIRE(energy && contact_idx, "fk_backward: the fused accept step needs the gqRowEnergyDesc and contact_idx");
+    GQ_REQUIRE(c.u_accept && c.step && c.energy && c.pose && c.idx && c.grad && c.accept && c.slot_ctr && c.slots > 0 &&
+                   c.annealing_period > 0 && (c.n_terms == 0 || (c.terms_new && c.terms)),
+               "fk_backward: incomplete gqAcceptDesc");
+    a.has_accept = 1;
+    a.ac.new_energy = energy->total;
+    a.ac.u_accept = c.u_accept;
+    a.ac.z = c.z;
+    a.ac.reset_mask = c.reset_mask;
+    a.ac.step = c.step;
+    a.ac.pose_new = hand_pose;
+    a.ac.idx_new = contact_idx;
+    a.ac.grad_new = grad_pose;
+    a.ac.B = (int)batch;
+    a.ac.D = 9 + h->J;
+    a.ac.n = n_contact;
+    a.ac.T0 = c.starting_temperature;
+    a.ac.decay = c.decay;
+    a.ac.annealing_period = c.annealing_period;
+    a.ac.energy = c.energy;
+    a.ac.pose = c.pose;
+    a.ac.idx = c.idx;
+    a.ac.grad = c.grad;
+    a.ac.accept = c.accept;
+    a.ac.temperature = c.temperature;
+    a.ac.n_terms = c.n_terms;
+    a.ac.terms_new = c.terms_new;
+    a.ac.terms = c.terms;
+    a.ac.slot_ctr = c.slot_ctr;
+    a.ac.slots = c.slots;
+  }
   GQ_REQUIRE(a.n + h->S <= GQ_FK_MAX_ITEMS, "fk_backward: n_contact + n_spheres = %d exceeds %d", a.n + h->S,
              GQ_FK_MAX_ITEMS);
   hipLaunchKernelGGL(gq_fk_backward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);

@@ -1,0 +1,140 @@
+// Device bodies of MalaStar.try_step / accept_step (core/optimizer.py:199-273, 289-340), shared by the stand-alone
+// kernels of loop.hip and the FK kernels of kin.hip, which run them as head / tail of the same wavefront.
+#pragma once
+#include "common.h"
+
+struct GqProposeArgs {
+  const float* hand_pose;
+  const float* grad;
+  const float* g2;        // (D)
+  const int64_t* idx;     // (B,n)
+  const float* u_switch;  // (B,n)
+  const int64_t* new_idx; // (B,n)
+  int B, D, n, clip;
+  float step_size, decay, mu, switch_p;
+  int stepsize_period;
+  float* ema;       // (B,D) in/out
+  int64_t* step;    // (B) in/out
+  float* pose_out;  // (B,D)
+  int64_t* idx_out; // (B,n)
+  float* s_out;     // (B) or null
+  const float* energy;  // (B) accepted energies or null
+  int batch_each;
+  float* z_out;     // (B) per-object z-score of `energy` (fit.py:403-406), written when energy != null
+  // fused form (gq_fk_forward with a gqProposeDesc): u_switch / new_idx hold `slots` iterations of draws and
+  // slot_ctr[0] selects the current one
+  int* slot_ctr;
+  int slots;
+};
+
+// one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
+__device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane) {
+  float g2[2];
+  g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
+  g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
+  const size_t draw0 = g.slot_ctr ? (size_t)(g.slot_ctr[0] % g.slots) * g.B * g.n : 0;
+  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[1] = g.slot_ctr[0] + 1;  // read by the accept of this iteration
+  const int64_t st = g.step[row];
+  const float s = g.step_size * powf(g.decay, (float)(st / g.stepsize_period));
+  float v[2] = {0.0f, 0.0f};
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = lane + GQ_WAVE * c;
+    if (d < g.D) {
+      const size_t o = (size_t)row * g.D + d;
+      float gr = g.grad[o];
+      if (g.clip) {
+        gr = fminf(fmaxf(gr, -100.0f), 100.0f);
+        if (gr != gr) gr = 0.0f;
+      }
+      float em = g.mu * g2[c] + (1.0f - g.mu) * g.ema[o];
+      if (em != em) em = 0.0f;
+      g.ema[o] = em;
+      v[c] = g.hand_pose[o] - s * gr / (sqrtf(em) + 1e-6f);
+      bad |= (v[c] != v[c]);
+    }
+  }
+  const bool zero_row = __ballot(bad) != 0ull;  // optimizer.py:242-244: a row with any NaN is zeroed
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = lane + GQ_WAVE * c;
+    if (d < g.D) g.pose_out[(size_t)row * g.D + d] = zero_row ? 0.0f : v[c];
+  }
+  for (int c = lane; c < g.n; c += GQ_WAVE) {
+    const size_t o = (size_t)row * g.n + c;
+    g.idx_out[o] = (g.u_switch[draw0 + o] < g.switch_p) ? g.new_idx[draw0 + o] : g.idx[o];
+  }
+  if (lane == 0) {
+    g.step[row] = st + 1;
+    if (g.s_out) g.s_out[row] = s;
+  }
+  if (g.energy) {  // z = (E - mean_obj) / std_obj (unbiased) over the rows of this row's object
+    const float* e = g.energy + (size_t)(row / g.batch_each) * g.batch_each;
+    float acc = 0.0f;
+    for (int i = lane; i < g.batch_each; i += GQ_WAVE) acc += e[i];
+    const float mean = gq_dpp_sum(acc) / (float)g.batch_each;
+    acc = 0.0f;
+    for (int i = lane; i < g.batch_each; i += GQ_WAVE) {
+      const float d = e[i] - mean;
+      acc = fmaf(d, d, acc);
+    }
+    const float sd = sqrtf(gq_dpp_sum(acc) / (float)(g.batch_each - 1));
+    if (lane == 0) g.z_out[row] = (g.energy[row] - mean) / sd;
+  }
+}
+
+struct GqAcceptArgs {
+  const float* new_energy;
+  const float* u_accept;
+  const float* z;            // (B) or null
+  const uint8_t* reset_mask; // (B) or null
+  const int64_t* step;       // post-propose counter
+  const float* pose_new;
+  const int64_t* idx_new;
+  const float* grad_new;
+  int B, D, n;
+  float T0, decay;
+  int annealing_period;
+  float* energy;   // (B) in/out
+  float* pose;     // (B,D) in/out (accepted state)
+  int64_t* idx;    // (B,n) in/out
+  float* grad;     // (B,D) in/out
+  uint8_t* accept; // (B)
+  float* temperature; // (B) or null
+  int n_terms;
+  const float* terms_new;  // (n_terms,B) or null
+  float* terms;            // (n_terms,B) or null
+  // fused form (gq_fk_backward with a gqAcceptDesc): u_accept holds `slots` iterations of draws; slot_ctr[1] - 1 is
+  // the current one (written by this iteration's propose), and slot_ctr[0] is advanced for the next iteration
+  int* slot_ctr;
+  int slots;
+};
+
+__device__ __forceinline__ void gq_accept_body(const GqAcceptArgs& g, int row, int lane) {
+  const size_t draw0 = g.slot_ctr ? (size_t)((g.slot_ctr[1] - 1) % g.slots) * g.B : 0;
+  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[0] = g.slot_ctr[1];
+  float T = g.T0 * powf(g.decay, (float)(g.step[row] / g.annealing_period));
+  if (g.z) {
+    const float proba = 0.5f * (1.0f + erff(g.z[row] * 0.70710678118654752f));
+    T = T * (1.0f + proba);
+  }
+  const float e_old = g.energy[row], e_new = g.new_energy[row];
+  bool acc = g.u_accept[draw0 + row] < expf((e_old - e_new) / T);
+  if (g.reset_mask && g.reset_mask[row]) acc = true;
+  if (lane == 0) {
+    g.accept[row] = acc ? 1 : 0;
+    if (g.temperature) g.temperature[row] = T;
+    if (acc) g.energy[row] = e_new;
+  }
+  if (acc) {  // wave-uniform
+    for (int d = lane; d < g.D; d += GQ_WAVE) {
+      const size_t o = (size_t)row * g.D + d;
+      g.pose[o] = g.pose_new[o];
+      g.grad[o] = g.grad_new[o];
+    }
+    for (int c = lane; c < g.n; c += GQ_WAVE) g.idx[(size_t)row * g.n + c] = g.idx_new[(size_t)row * g.n + c];
+    for (int t = lane; t < g.n_terms; t += GQ_WAVE) g.terms[(size_t)t * g.B + row] = g.terms_new[(size_t)t * g.B + row];
+  }
+}
+

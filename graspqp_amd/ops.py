@@ -358,7 +358,7 @@ class _FK(torch.autograd.Function):
         sc = torch.empty(B, max(hand.S, 1), 3, device=dev)
         ws, nb = hand.fk_ws(B, dev)
         _C.call("gq_fk_forward", hand.handle, _C.f32(hp), _C.i64(ix), B, n, _C.f32(Rg), _C.f32(LT), _C.f32(cp),
-                _C.f32(cn), _C.f32(sc) if hand.S > 0 else None, 0.0, None, None, _C.ptr(ws), nb, _C.stream_ptr())
+                _C.f32(cn), _C.f32(sc) if hand.S > 0 else None, 0.0, None, None, None, _C.ptr(ws), nb, _C.stream_ptr())
         ctx.save_for_backward(hp, ix, Rg, LT, ws)
         ctx.hand = hand
         ctx.nb = nb
@@ -382,7 +382,7 @@ def _fk_backward(hand, hp, ix, Rg, LT, ws, nb, gcp, gcn, gsc, wrench, gRt, gthet
             _C.f32(None if gcp is None else _c(gcp)), _C.f32(None if gcn is None else _c(gcn)),
             _C.f32(None if (gsc is None or hand.S == 0) else _c(gsc)), _C.f32(None if wrench is None else _c(wrench)),
             _C.f32(None if gRt is None else _c(gRt)), _C.f32(None if gtheta is None else _c(gtheta)),
-            _C.f32(None if gR is None else _c(gR)), _C.f32(gp), None, _C.ptr(ws), nb, _C.stream_ptr())
+            _C.f32(None if gR is None else _c(gR)), _C.f32(gp), None, None, _C.ptr(ws), nb, _C.stream_ptr())
     return gp
 
 

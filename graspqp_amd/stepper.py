@@ -91,7 +91,7 @@ class GraspStepper:
         if int(penetration_only) == 3:  # queue path of the penetration query (A/B tests); counters start at zero
             self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
             self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)
-        self._graph = None
+        self._graph, self._graph_iters, self._graph_pending = None, 1, 0
         self.kernel_events = None
         self._span = torch.zeros(64, 2, dtype=torch.int64, device=self.dev)
         self._span[:, 0] = -1  # {~0, 0}: armed
@@ -127,17 +127,39 @@ class GraspStepper:
                                                       self.terms_new[2].data_ptr())
         pd.span, pd.span_acc = self._span.data_ptr(), self._span_acc.data_ptr()
         self._fc_desc, self._pen_desc = fd, pd
+        # MalaStar.try_step / accept_step as head / tail of the FK kernels
+        self._fuse_loop = True
+        self._slot_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        m, pr = self.mala, _C.ProposeDesc()
+        pr.hand_pose, pr.grad, pr.contact_idx = self.hand_pose.data_ptr(), self.grad.data_ptr(), self.contact_idx.data_ptr()
+        pr.u_switch, pr.new_idx = self._u_sw.data_ptr(), self._n_ix.data_ptr()
+        pr.ema, pr.step, pr.step_size_out = self.ema.data_ptr(), self.step_count.data_ptr(), self.s_out.data_ptr()
+        pr.g2_scratch = self.g2.data_ptr()
+        pr.energy, pr.batch_each, pr.z_out = self.energy.data_ptr(), self.be, self.z.data_ptr()
+        pr.step_size, pr.stepsize_period, pr.decay = float(m["step_size"]), int(m["stepsize_period"]), float(m["temperature_decay"])
+        pr.mu, pr.switch_possibility, pr.clip_grad = float(m["mu"]), float(m["switch_possibility"]), int(bool(m["clip_grad"]))
+        pr.slot_ctr, pr.slots = self._slot_ctr.data_ptr(), 64
+        ac = _C.AcceptDesc()
+        ac.u_accept, ac.z, ac.reset_mask, ac.step = self._u_ac.data_ptr(), self.z.data_ptr(), None, self.step_count.data_ptr()
+        ac.starting_temperature, ac.decay, ac.annealing_period = (float(m["starting_temperature"]), float(m["temperature_decay"]),
+                                                                  int(m["annealing_period"]))
+        ac.energy, ac.pose, ac.idx, ac.grad = (t.data_ptr() for t in (self.energy, self.hand_pose, self.contact_idx, self.grad))
+        ac.accept, ac.temperature = self.accept.data_ptr(), self.temperature.data_ptr()
+        ac.n_terms, ac.terms_new, ac.terms = 5, self.terms_new.data_ptr(), self.terms.data_ptr()
+        ac.slot_ctr, ac.slots = self._slot_ctr.data_ptr(), 64
+        self._propose_desc, self._accept_desc = pr, ac
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
     # Four pieces: FK (+ self penetration), then two independent branches (contacts -> object SDF -> E_fc fwd+bwd |
     # hand penetration fwd+bwd), then FK backward with the row energies.  ``_evaluate`` runs the branches on two
     # streams when ``fork`` is set (inside a hipGraph capture they become parallel graph branches).
-    def _eval_fk(self, pose, idx, st):
+    def _eval_fk(self, pose, idx, st, loop=False):
         B, n = self.B, self.n
         _C.call("gq_fk_forward", self.hand.handle, _C.f32(pose), _C.i64(idx), B, n, _C.f32(self.Rg), _C.f32(self.link_T),
                 _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None,
                 float(self.w["E_spen"]), _C.f32(self.terms_new[3]) if self.S > 0 else None,
-                _C.f32(self.g_sph_w) if self.S > 0 else None, _C.ptr(self.fk_ws), self.fk_nb, st)
+                _C.f32(self.g_sph_w) if self.S > 0 else None, ctypes.byref(self._propose_desc) if loop else None,
+                _C.ptr(self.fk_ws), self.fk_nb, st)
         if self.S == 0:
             _C.call("gq_fill", _C.f32(self.terms_new[3]), 0.0, self.B, st)
 
@@ -167,16 +189,18 @@ class GraspStepper:
                 _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),
                 _C.ptr(self._span_acc), st)
 
-    def _eval_tail(self, pose, idx, st):
+    def _eval_tail(self, pose, idx, st, loop=False):
         B, n = self.B, self.n
         f32 = _C.f32
         _C.call("gq_fk_backward", self.hand.handle, f32(pose), _C.i64(idx), B, n, f32(self.Rg), f32(self.link_T),
                 f32(self.g_cpts), f32(self.g_cnrm), f32(self.g_sph_w) if self.S > 0 else None, f32(self.wrench),
-                f32(self.gRt), None, None, f32(self.grad_new), ctypes.byref(self._row_energy), _C.ptr(self.fk_ws),
-                self.fk_nb, st)
+                f32(self.gRt), None, None, f32(self.grad_new), ctypes.byref(self._row_energy),
+                ctypes.byref(self._accept_desc) if loop else None, _C.ptr(self.fk_ws), self.fk_nb, st)
 
-    def _evaluate(self, pose, idx, st, fork=False, timer=None, fused=False):
-        self._eval_fk(pose, idx, st)
+    def _evaluate(self, pose, idx, st, fork=False, timer=None, fused=False, loop=False):
+        """loop=True: one whole MALA* iteration -- the proposal is the head of the FK forward kernel (pose / idx are its
+        outputs), the accept step the tail of the FK backward kernel."""
+        self._eval_fk(pose, idx, st, loop)
         if fused:
             # object SDF of the contacts, then both branches side by side in two launches
             _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,
@@ -193,7 +217,7 @@ class GraspStepper:
             self._eval_contacts(st)
             self._eval_pen(pose, ctypes.c_void_p(sb.cuda_stream), timer)
             main.wait_stream(sb)
-        self._eval_tail(pose, idx, st)
+        self._eval_tail(pose, idx, st, loop)
 
     def evaluate(self, pose, idx):
         """Energy terms, total and d total / d pose at an arbitrary (pose, idx); returns clones."""
@@ -214,11 +238,16 @@ class GraspStepper:
         self.ema.zero_()
         self.step_count.zero_()
 
-    def draw(self):
+    def draw(self, draws=None):
         """Random draws of one iteration (optimizer.py:253-257,305): full-size draws + select (no host sync),
-        generated 64 iterations at a time and sliced per iteration (3 generator launches per 64 iterations)."""
+        generated 64 iterations at a time (3 generator launches per 64 iterations).  The kernels pick the current slot
+        themselves (device counter ``_slot_ctr``, mirrored by ``_draw_pos``).  ``draws`` injects one iteration."""
         k = self._draw_pos
-        if k == 0:
+        if draws is not None:
+            self._u_sw[k].copy_(draws[0])
+            self._n_ix[k].copy_(draws[1])
+            self._u_ac[k].copy_(draws[2])
+        elif k == 0:
             self._u_sw.uniform_(generator=self.gen)
             self._n_ix.random_(0, self.hand.spec.n_contact_candidates, generator=self.gen)
             self._u_ac.uniform_(generator=self.gen)
@@ -266,35 +295,61 @@ class GraspStepper:
         self.kernel_events = None
         return ev_ms, span_ms, n
 
+    def _iteration(self, st, timer=None, fork=False, fused=False):
+        """One MALA* iteration as launches on ``st`` (eager, or under hipGraph capture)."""
+        if self._fuse_loop:
+            self._evaluate(self.pose_new, self.idx_new, st, fork=fork, timer=timer, fused=fused, loop=True)
+        else:
+            self._propose(st)
+            self._evaluate(self.pose_new, self.idx_new, st, fork=fork, timer=timer, fused=fused)
+            self._accept(st)
+
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""
-        if draws is None:
-            self.draw()
-        else:
-            self.u_switch.copy_(draws[0])
-            self.new_idx.copy_(draws[1])
-            self.u_accept.copy_(draws[2])
-            self._cur = (self.u_switch, self.new_idx, self.u_accept)
+        if self._graph_pending and self._draw_pos == 0:
+            self.flush()  # queued iterations still need the draws that the refill below would overwrite
+        self.draw(draws)
         st = _C.stream_ptr()
-        self._propose(st)
-        if self._graph is not None:
+        if self._graph is not None and self._fuse_loop:
+            if self._graph_iters > 1:  # the captured graph holds several iterations: replay it once per group
+                self._graph_pending += 1
+                if self._graph_pending == self._graph_iters:
+                    self._graph.replay()
+                    self._graph_pending = 0
+                return
             self._graph.replay()
+        elif self._graph is not None:
+            self._propose(st)
+            self._graph.replay()
+            self._accept(st)
         else:
             timer = None
             if self.kernel_events is not None and len(self.kernel_events) < 4096:
                 timer = ctypes.c_void_p(0)
                 _C.call("gq_timer_create", ctypes.byref(timer))
                 self.kernel_events.append(timer)
-            self._evaluate(self.pose_new, self.idx_new, st, timer=timer)
-        self._accept(st)
+            self._iteration(st, timer=timer)
 
-    def capture(self, fork=False, fused=True):
-        """Capture the energy + gradient evaluation of one iteration into a hipGraph whose three independent branches
-        (contacts/object SDF/E_fc | hand penetration | self penetration) may run concurrently.  Propose and accept stay
-        ordinary launches: they read the current slice of the pre-generated random numbers.  The state is saved and
-        restored around the warm-up + capture passes, so capturing does not advance the chain."""
-        saved = [t.clone() for t in (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema,
-                                     self.step_count, self.terms, self._span_acc)]
+    def flush(self):
+        """Run the iterations that ``step`` has queued for a multi-iteration graph but not yet replayed."""
+        if self._graph_pending:
+            st = _C.stream_ptr()
+            for _ in range(self._graph_pending):
+                self._iteration(st, fused=self.penetration_only == 1)
+            self._graph_pending = 0
+
+    def capture(self, fork=False, fused=True, iters=1):
+        """Capture one iteration into a hipGraph: FK forward (with the proposal as its head and the self-penetration
+        term), object SDF of the contacts, the two stage launches that hold the force-closure and the penetration
+        branch side by side (``fused``; ``fork`` = the branches as parallel graph branches instead, for A/B runs), FK
+        backward (with the energies and the accept step as its tail) -- five launches, no host involvement.  ``iters``
+        > 1 captures that many consecutive iterations in one graph (every kernel finds its random draws through the
+        device-side slot counter), which removes the graph-launch gap between iterations; ``step`` then replays once
+        per ``iters`` calls and ``flush`` runs a remainder.  The state is saved and restored around the warm-up +
+        capture passes, so capturing does not advance the chain."""
+        keep = (self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema, self.step_count, self.terms,
+                self._span_acc, self._slot_ctr)
+        saved = [t.clone() for t in keep]
         rng = (self.gen.get_state(), self._draw_pos)
         fused = fused and self.penetration_only == 1
         fork = fork and not fused
@@ -304,20 +359,22 @@ class GraspStepper:
         s.wait_stream(torch.cuda.current_stream())
         self.draw()
         with torch.cuda.stream(s):
-            st = _C.stream_ptr()
-            self._propose(st)
-            self._evaluate(self.pose_new, self.idx_new, st, fork=fork, fused=fused)
-            self._accept(st)
+            self._iteration(_C.stream_ptr(), fork=fork, fused=fused)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        iters = iters if self._fuse_loop else 1
+        assert 64 % iters == 0, "iters must divide the 64-slot draw buffer"
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._evaluate(self.pose_new, self.idx_new, _C.stream_ptr(), fork=fork, fused=fused)
+            if self._fuse_loop:
+                for _ in range(iters):
+                    self._iteration(_C.stream_ptr(), fork=fork, fused=fused)
+            else:
+                self._evaluate(self.pose_new, self.idx_new, _C.stream_ptr(), fork=fork, fused=fused)
         torch.cuda.synchronize()
-        for t, v in zip((self.hand_pose, self.contact_idx, self.grad, self.energy, self.ema, self.step_count,
-                         self.terms, self._span_acc), saved):
+        for t, v in zip(keep, saved):
             t.copy_(v)
         self.gen.set_state(rng[0])
         self._draw_pos = rng[1]
-        self._graph = g
+        self._graph, self._graph_iters, self._graph_pending = g, iters, 0
         return g

@@ -143,13 +143,37 @@ typedef struct gqHandDesc { /* all pointers HOST */
 typedef struct gqHand gqHand;
 int gq_hand_create(const gqHandDesc* desc, gqHand** out);
 int gq_hand_destroy(gqHand* h);
+/* Optional head of gq_fk_forward / tail of gq_fk_backward: MalaStar.try_step and MalaStar.accept_step
+ * (core/optimizer.py:199-273, 289-340; parameters as gq_mala_propose / gq_mala_accept) run in the same wavefront as
+ * the row's kinematics, so an iteration needs no launch of its own for them.  u_switch / new_idx / u_accept hold
+ * `slots` iterations of random draws, (slots,B,n) / (slots,B,n) / (slots,B); slot_ctr (2 x int32, device, zeroed
+ * once) selects the current slot and is advanced on the device, so that the whole iteration can be replayed from a
+ * hipGraph: the host refills the buffers every `slots` iterations.                                               */
+typedef struct gqProposeDesc {
+  const float* hand_pose;      /* (B,D) accepted pose; the proposal goes to gq_fk_forward's hand_pose argument      */
+  const float* grad;           /* (B,D) */
+  const int64_t* contact_idx;  /* (B,n) accepted indices; the proposal goes to gq_fk_forward's contact_idx argument */
+  const float* u_switch; const int64_t* new_idx;
+  float* ema; int64_t* step; float* step_size_out /* (B) or NULL */; float* g2_scratch /* (D) */;
+  const float* energy /* (B) or NULL */; int64_t batch_each; float* z_out;
+  float step_size; int32_t stepsize_period; float decay, mu, switch_possibility; int32_t clip_grad;
+  int32_t* slot_ctr; int32_t slots;
+} gqProposeDesc;
+typedef struct gqAcceptDesc {
+  const float* u_accept; const float* z; const uint8_t* reset_mask; const int64_t* step;
+  float starting_temperature, decay; int32_t annealing_period;
+  float* energy; float* pose; int64_t* idx; float* grad; uint8_t* accept; float* temperature;
+  int32_t n_terms; const float* terms_new; float* terms;
+  int32_t* slot_ctr; int32_t slots;
+} gqAcceptDesc;
 int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes);
 int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx /* (B,n) */, int64_t batch,
                   int n_contact, float* Rg /* (B,9) */, float* link_T /* (B,L,12) */, float* contact_points /* (B,n,3) */,
                   float* contact_normals /* (B,n,3) */, float* sphere_centers /* (B,S,3) or NULL */,
                   float spen_scale, float* e_spen /* (B) or NULL: gq_self_pen_forward fused in */,
-                  float* g_sphere_centers /* (B,S,3), with e_spen: spen_scale * dE_spen/dcentre */, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  float* g_sphere_centers /* (B,S,3), with e_spen: spen_scale * dE_spen/dcentre */,
+                  const gqProposeDesc* propose /* NULL, or: hand_pose / contact_idx are first WRITTEN by the proposal */,
+                  void* workspace, size_t workspace_bytes, void* stream);
 /* Optional tail of gq_fk_backward: E_dis, E_joints (with its gradient) and the weighted total of one row
  * (core/energy.py:25-28,47-54; scripts/fit.py:434-438), so the iteration needs no separate reduction launch.     */
 typedef struct gqRowEnergyDesc {
@@ -174,8 +198,9 @@ typedef struct gqRowEnergyDesc {
 int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                    const float* Rg, const float* link_T, const float* g_contact_points, const float* g_contact_normals,
                    const float* g_sphere_centers, const float* g_link_wrench, const float* g_Rt, const float* g_theta,
-                   const float* g_R, float* grad_pose /* (B,9+J) */, const gqRowEnergyDesc* energy, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   const float* g_R, float* grad_pose /* (B,9+J) */, const gqRowEnergyDesc* energy,
+                   const gqAcceptDesc* accept /* NULL, or the Metropolis test on energy->total + state merge */,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
  * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.

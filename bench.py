@@ -175,8 +175,19 @@ def main():
             alg = B * st.P * hand.L * 16 + nf * 36
             ach = alg / (k_ms * 1e-3) / 1e9
             pair_tests = B * st.P * nf  # what the reference's brute force executes; AABB culling skips most of them
-            roof = {"bound": "hbm", "kernel": "gq_pen_grid_kernel (gq_hand_pen_forward)", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                    "frac": ach / 8000.0, "traffic": None, "kernel_ms": k_ms, "kernel_launches_timed": n_span,
+            # HBM bytes per launch of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs; tools/pmc_traffic.py applies the gfx950 FETCH_SIZE x2 correction) -- measured with the profiler, so
+            # it is read from the committed summary of this round rather than collected inside the timed run
+            traffic, tsrc = None, None
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            if args.hand == "allegro" and args.batch_size == 256 and args.n_objects == 1 and os.path.exists(tp):
+                pm = json.load(open(tp)).get("gq_pen_grid_kernel<true>")
+                if pm:
+                    traffic, tsrc = pm["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+            roof = {"bound": "hbm", "kernel": "gq_pen_grid_kernel (hand-penetration query; in the graph it runs as the "
+                                              "pen role of gq_stage_a_kernel)",
+                    "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                    "traffic_source": tsrc, "kernel_ms": k_ms, "kernel_launches_timed": n_span,
                     "kernel_ms_isolated": span_iso_ms, "kernel_ms_isolated_hip_events": k_ms_events,
                     "algorithmic_bytes": alg,
                     "bruteforce_equivalent_point_triangle_tests_per_s": pair_tests / (k_ms * 1e-3)}

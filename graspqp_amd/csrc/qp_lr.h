@@ -103,8 +103,9 @@ struct GqLr {
       float s = 0.0f;
 #pragma unroll
       for (int c = 0; c < NC; ++c) s = fmaf(a[c][i], x[c], s);
-      ax[i] = gq_dpp_sum(s);
+      ax[i] = s;
     }
+    gq_wave_sums_f<M>(ax);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       float s = ridge * x[c];
@@ -115,10 +116,17 @@ struct GqLr {
   }
 };
 
+// qpth get_step ratio -v/dv (blocking only for dv < 0) with the hardware reciprocal; zeros and infinities behave like the
+// IEEE division (dv = +-0 -> -+inf, 0/0 -> NaN)
+__device__ __forceinline__ float gq_step_ratio_rcp(float v, float dv) {
+  const float a = -v * __builtin_amdgcn_rcpf(dv);
+  return (dv > 0.0f) ? GQ_INF : a;
+}
+
 // reduced-KKT solve for my columns (see gq_kkt_solve in qp_core.h)
 template <int M, int NC>
 __device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du)[NC], const float (&dl)[NC],
-                                          const float (&rx)[NC], const float (&rsu)[NC], const float (&rsl)[NC],
+                                          const float (&idu)[NC], const float (&idl)[NC], const float (&rx)[NC], const float (&rsu)[NC], const float (&rsl)[NC],
                                           const float (&rzu)[NC], const float (&rzl)[NC], float (&dx)[NC],
                                           float (&dsu)[NC], float (&dsl)[NC], float (&dzu)[NC], float (&dzl)[NC]) {
   float rhs[NC];
@@ -132,8 +140,8 @@ __device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du
   for (int c = 0; c < NC; ++c) {
     dzu[c] = du[c] * (dx[c] + rzu[c]) - rsu[c];
     dzl[c] = dl[c] * (-dx[c] + rzl[c]) - rsl[c];
-    dsu[c] = (-rsu[c] - dzu[c]) / du[c];
-    dsl[c] = (-rsl[c] - dzl[c]) / dl[c];
+    dsu[c] = (-rsu[c] - dzu[c]) * idu[c];  // idu = 1 / du
+    dsl[c] = (-rsl[c] - dzl[c]) * idl[c];
   }
 }
 
@@ -156,7 +164,7 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
   }
   // ---- initial point: solve_kkt(d = 1, rx = p, rs = 0, rz = -h) ----------------------------------------------
   S.factor(lam, live);
-  gq_lr_kkt<M, NC>(S, ones, ones, p, zero, zero, nhu, nhl, x, su, sl, zu, zl);
+  gq_lr_kkt<M, NC>(S, ones, ones, ones, ones, p, zero, zero, nhu, nhl, x, su, sl, zu, zl);
   {
     float ms = GQ_INF, mz = GQ_INF;
 #pragma unroll
@@ -201,9 +209,11 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
         a_rx += rx[c] * rx[c];
       }
     }
-    const float sz = gq_dpp_sum(a_sz);
+    float red[3] = {a_sz, a_rz, a_rx};
+    gq_wave_sums_f<3>(red);
+    const float sz = red[0];
     const float mu = fabsf(sz / m2);
-    const float resid = sqrtf(gq_dpp_sum(a_rz)) + sqrtf(gq_dpp_sum(a_rx)) + m2 * mu;
+    const float resid = sqrtf(red[1]) + sqrtf(red[2]) + m2 * mu;
     const bool record = (it == 0) || (resid < best);  // false for NaN: a NaN iterate never becomes best
     if (record) {
       best = resid;
@@ -225,22 +235,27 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
     }
     if (it == g.max_iter - 1) break;  // qpth returns `best` after the loop; the last update is never used
 
-    float du[NC], dl[NC];
+    // reciprocals of s and z once per iteration (v_rcp_f32, 1 ulp): d = z/s, 1/d = s/z, and the corrector's 1/s
+    float du[NC], dl[NC], idu[NC], idl[NC], isu[NC], isl[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      du[c] = zu[c] / su[c];
-      dl[c] = zl[c] / sl[c];
+      isu[c] = __builtin_amdgcn_rcpf(su[c]);
+      isl[c] = __builtin_amdgcn_rcpf(sl[c]);
+      du[c] = zu[c] * isu[c];
+      dl[c] = zl[c] * isl[c];
+      idu[c] = su[c] * __builtin_amdgcn_rcpf(zu[c]);
+      idl[c] = sl[c] * __builtin_amdgcn_rcpf(zl[c]);
       lam[c] = g.ridge + du[c] + dl[c];
     }
     S.factor(lam, live);
     float dxa[NC], dsua[NC], dsla[NC], dzua[NC], dzla[NC];
-    gq_lr_kkt<M, NC>(S, du, dl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
+    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
     float st = GQ_INF;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
       if (live[c])
-        st = gq_nanmin(st, gq_nanmin(gq_nanmin(gq_step_ratio(zu[c], dzua[c]), gq_step_ratio(zl[c], dzla[c])),
-                                     gq_nanmin(gq_step_ratio(su[c], dsua[c]), gq_step_ratio(sl[c], dsla[c]))));
+        st = gq_nanmin(st, gq_nanmin(gq_nanmin(gq_step_ratio_rcp(zu[c], dzua[c]), gq_step_ratio_rcp(zl[c], dzla[c])),
+                                     gq_nanmin(gq_step_ratio_rcp(su[c], dsua[c]), gq_step_ratio_rcp(sl[c], dsla[c]))));
     float alpha = gq_nanmin(gq_dpp_nanmin(st), 1.0f);
     float a_t3 = 0.0f;
 #pragma unroll
@@ -252,11 +267,11 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
     float rs2u[NC], rs2l[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      rs2u[c] = (-mu * sig + dsua[c] * dzua[c]) / su[c];
-      rs2l[c] = (-mu * sig + dsla[c] * dzla[c]) / sl[c];
+      rs2u[c] = (-mu * sig + dsua[c] * dzua[c]) * isu[c];
+      rs2l[c] = (-mu * sig + dsla[c] * dzla[c]) * isl[c];
     }
     float dxc[NC], dsuc[NC], dslc[NC], dzuc[NC], dzlc[NC];
-    gq_lr_kkt<M, NC>(S, du, dl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc);
+    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc);
     st = GQ_INF;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -266,8 +281,8 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
       dzua[c] += dzuc[c];
       dzla[c] += dzlc[c];
       if (live[c])
-        st = gq_nanmin(st, gq_nanmin(gq_nanmin(gq_step_ratio(zu[c], dzua[c]), gq_step_ratio(zl[c], dzla[c])),
-                                     gq_nanmin(gq_step_ratio(su[c], dsua[c]), gq_step_ratio(sl[c], dsla[c]))));
+        st = gq_nanmin(st, gq_nanmin(gq_nanmin(gq_step_ratio_rcp(zu[c], dzua[c]), gq_step_ratio_rcp(zl[c], dzla[c])),
+                                     gq_nanmin(gq_step_ratio_rcp(su[c], dsua[c]), gq_step_ratio_rcp(sl[c], dsla[c]))));
     }
     alpha = gq_nanmin(0.999f * gq_dpp_nanmin(st), 1.0f);
 #pragma unroll

@@ -1,10 +1,11 @@
 // Two "stage" kernels that run the force-closure branch and the hand-penetration branch of one MALA* iteration side by
 // side in the SAME launch (the branches are independent until the FK backward, scripts/fit.py:434-438):
 //
-//   stage A   blocks [0, B)        fc head   contact terms + cone matrix + all QP iterations of row b   (wave 0 only)
-//             blocks [B, B + gx B) pen query penetration-only hand query of 256 surface points of one row
-//   stage B   blocks [0, B)        fc tail   stop rule + E_fc + QP backward + contact gradient          (wave 0 only)
-//             blocks [B, 2B)       pen bwd   link wrenches + E_pen of one row
+//   stage A   blocks [0, B/4)        fc head   contact terms + cone matrix + all QP iterations; 4 rows per block,
+//                                              one wavefront (SIMD) each
+//             blocks [B/4, .. + gx B) pen query penetration-only hand query of 256 surface points of one row
+//   stage B   blocks [0, B)          fc tail   stop rule + E_fc + QP backward + contact gradient (wave 0 only)
+//             blocks [B, 2B)         pen bwd   link wrenches + E_pen of one row
 //
 // With B = 256 rows neither branch fills 256 CUs on its own (the QP is one wavefront per row), and separate streams
 // cost 20..100 us of cross-queue dependency latency per iteration on this platform; putting both roles in one grid gives
@@ -17,14 +18,15 @@ int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream);
 
 template <int NC>
-__global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx) {
+__global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
-  if (b < f.B) {
-    if (threadIdx.x >= GQ_WAVE) return;
-    gq_fc_head_body<NC>(f, b, reinterpret_cast<float*>(gq_lds));
+  if (b < nfc) {  // four rows per block, one wavefront (= one SIMD) each: the fc role occupies B/4 CUs only
+    const int wv = (int)threadIdx.x / GQ_WAVE, row = b * 4 + wv;
+    if (row >= f.B) return;
+    gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6);
   } else {
-    const int q = b - f.B;
+    const int q = b - nfc;
     gq_pen_grid_body<true>(p, q % gx, q / gx, gq_lds);
   }
 }
@@ -33,7 +35,7 @@ template <int NC, int RPL>
 __global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBwdArgs p) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
-  if (b < f.B) {
+  if (b < f.B) {  // one row per block here: 2B blocks = two per CU at B = 256, every tail wavefront has a CU's L1 to itself
     if (threadIdx.x >= GQ_WAVE) return;
     gq_fc_tail_body<NC, RPL>(f, b, reinterpret_cast<float*>(gq_lds));
   } else {
@@ -67,11 +69,12 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   if (rc) return rc;
   const int gx = (p.P + 255) / 256;
   const bool two = f.nz > GQ_WAVE;
-  const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)f.n * 6 * sizeof(float));
+  const int nfc = (f.B + 3) / 4;
+  const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)4 * f.n * 6 * sizeof(float));
   const size_t lds_b = std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float));
-  const dim3 grid_a((unsigned)(f.B + gx * p.B)), grid_b((unsigned)(2 * f.B)), block(256);
-  if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx);
-  else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx);
+  const dim3 grid_a((unsigned)(nfc + gx * p.B)), grid_b((unsigned)(2 * f.B)), block(256);
+  if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx, nfc);
+  else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx, nfc);
   GQ_LAUNCH_CHECK();
   const bool fused_stop = f.B <= 4 * GQ_WAVE && f.max_iter <= 16;
   if (!fused_stop) {

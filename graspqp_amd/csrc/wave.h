@@ -82,6 +82,44 @@ __device__ __forceinline__ void gq_wave_sums_d(double (&v)[K]) {
   }
 }
 
+// fp32 version of gq_wave_sums_d
+__device__ __forceinline__ float gq_fold32_f(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(y), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float gq_fold16_f(float x, float y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float gq_dpp_all_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ void gq_wave_sums_f(float (&v)[K]) {
+  constexpr int K1 = (K + 1) / 2, K2 = (K1 + 1) / 2;
+  float s1[K1], s2[K2];
+#pragma unroll
+  for (int i = 0; i < K1; ++i) s1[i] = gq_fold32_f(v[2 * i], (2 * i + 1 < K) ? v[2 * i + 1] : 0.0f);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] = gq_fold16_f(s1[2 * i], (2 * i + 1 < K1) ? s1[2 * i + 1] : 0.0f);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) {
+    float t = s2[i];
+    t += gq_dpp_all_f<0xb1>(t);   // quad_perm [1,0,3,2]
+    t += gq_dpp_all_f<0x4e>(t);   // quad_perm [2,3,0,1]
+    t += gq_dpp_all_f<0x141>(t);  // row_half_mirror
+    t += gq_dpp_all_f<0x140>(t);  // row_mirror
+    s2[i] = t;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = k / 4, q = k % 4;
+    const int src_lane = (q == 0) ? 0 : (q == 2) ? 16 : (q == 1) ? 32 : 48;
+    v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2[i]), src_lane));
+  }
+}
+
 // LDS hand-over between the lanes of ONE wavefront (blocks whose other wavefronts have exited, or single-wave blocks):
 // LDS operations of a wavefront execute in order, so only the compiler has to be kept from moving them.
 __device__ __forceinline__ void gq_wave_sync() {

@@ -127,23 +127,55 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ float sRad[256];
   const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
+  // The constant hand tables this lane needs (its joint node, its link, its first sphere, its sphere group) are loaded
+  // BEFORE anything else: a single wavefront per row hides no latency, and the barriers / fences below would otherwise
+  // turn every table into a dependent memory round trip of its own.
+  int parent = -1, depth = -1, ntype = 0, lnode = -1, slink = 0, ga0 = 0, ga1 = 0;
+  GqT pre = gq_t_identity(), loff = gq_t_identity();
+  gq3 ax = gq_mk(0, 0, 0);
+  float sph[4] = {0, 0, 0, 0};
+  if (lane < h.J) {
+    parent = h.node_parent[lane];
+    depth = h.node_depth[lane];
+    ntype = h.node_type[lane];
+    pre = gq_t_load(h.node_pre + lane * 12);
+    ax = gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]);
+  }
+  if (lane < h.L) {
+    lnode = h.link_node[lane];
+    loff = gq_t_load(h.link_offset + lane * 12);
+  }
+  if (g.spheres && lane < h.S) {
+    slink = h.sphere_link[lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sph[k] = h.sphere[lane * 4 + k];
+  }
+  const int ng = g.e_spen ? min(h.NG - 1, 64) : 0;  // the last sphere group has nothing after it
+  if ((lane >> 2) < ng) {
+    ga0 = h.group_off[lane >> 2];
+    ga1 = h.group_off[(lane >> 2) + 1];
+  }
   if (g.has_propose) {  // the proposal of this row, then its forward kinematics
     gq_propose_body(g.pr, row, lane);
     __threadfence_block();
   }
   const float* hp = g.hand_pose + (size_t)row * g.D;
+  // contact candidates of the (just proposed) indices: in flight while the tree is walked
+  int cl0 = 0;
+  gq3 cp0 = gq_mk(0, 0, 0), cn0 = gq_mk(0, 0, 0);
+  if (lane < g.n) {
+    const int ci = (int)g.idx[(size_t)row * g.n + lane];
+    cl0 = h.cand_link[ci];
+    cp0 = gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]);
+    cn0 = gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]);
+  }
   float R[9];
   gq_rot6d(hp + 3, R);
   if (lane < 9) g.Rg[(size_t)row * 9 + lane] = R[lane];
   const gq3 tg = gq_mk(hp[0], hp[1], hp[2]);
   GqT A = gq_t_identity();
-  int parent = -1, depth = -1;
   if (lane < h.J) {
-    parent = h.node_parent[lane];
-    depth = h.node_depth[lane];
-    const GqT pre = gq_t_load(h.node_pre + lane * 12);
-    const gq3 ax = gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]);
-    A = gq_t_mul(pre, gq_joint_motion(h.node_type[lane], ax, hp[9 + lane]));
+    A = gq_t_mul(pre, gq_joint_motion(ntype, ax, hp[9 + lane]));
     if (parent < 0) gq_t_store(sW + lane * 12, A);
   }
   __syncthreads();
@@ -156,20 +188,24 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
   }
   if (lane < h.J) gq_t_store(g.node_W + ((size_t)row * h.J + lane) * 12, A);
   if (lane < h.L) {
-    const int nd = h.link_node[lane];
-    GqT T = gq_t_load(h.link_offset + lane * 12);
-    if (nd >= 0) T = gq_t_mul(gq_t_load(sW + nd * 12), T);
+    GqT T = loff;
+    if (lnode >= 0) T = gq_t_mul(gq_t_load(sW + lnode * 12), T);
     gq_t_store(sT + lane * 12, T);
     gq_t_store(g.link_T + ((size_t)row * h.L + lane) * 12, T);
   }
   __syncthreads();
   for (int c = lane; c < g.n; c += GQ_WAVE) {
-    const int ci = (int)g.idx[(size_t)row * g.n + c];
-    const GqT T = gq_t_load(sT + h.cand_link[ci] * 12);
-    const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
-    const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
-    const gq3 pw = gq_mv(R, ph) + tg;
-    const gq3 nw = gq_mv(R, nh);
+    int cl = cl0;
+    gq3 cp = cp0, cn = cn0;
+    if (c >= GQ_WAVE) {
+      const int ci = (int)g.idx[(size_t)row * g.n + c];
+      cl = h.cand_link[ci];
+      cp = gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]);
+      cn = gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]);
+    }
+    const GqT T = gq_t_load(sT + cl * 12);
+    const gq3 pw = gq_mv(R, gq_t_apply(T, cp)) + tg;
+    const gq3 nw = gq_mv(R, gq_t_rot(T, cn));
     float* o = g.cpts + ((size_t)row * g.n + c) * 3;
     o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
     o = g.cnrm + ((size_t)row * g.n + c) * 3;
@@ -177,13 +213,20 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
   }
   if (g.spheres) {
     for (int sidx = lane; sidx < h.S; sidx += GQ_WAVE) {
-      const GqT T = gq_t_load(sT + h.sphere_link[sidx] * 12);
-      const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[sidx * 4], h.sphere[sidx * 4 + 1], h.sphere[sidx * 4 + 2]));
-      const gq3 pw = gq_mv(R, ph) + tg;
+      int sl = slink;
+      float sp4[4] = {sph[0], sph[1], sph[2], sph[3]};
+      if (sidx >= GQ_WAVE) {
+        sl = h.sphere_link[sidx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sp4[k] = h.sphere[sidx * 4 + k];
+      }
+      const GqT T = gq_t_load(sT + sl * 12);
+      const gq3 pw = gq_mv(R, gq_t_apply(T, gq_mk(sp4[0], sp4[1], sp4[2]))) + tg;
       float* o = g.spheres + ((size_t)row * h.S + sidx) * 3;
       o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
       if (g.e_spen) {
         sC[sidx * 3] = pw.x; sC[sidx * 3 + 1] = pw.y; sC[sidx * 3 + 2] = pw.z;
+        sRad[sidx] = sp4[3];
       }
     }
   }
@@ -191,11 +234,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
     // Self penetration (hand_model.py:989-1040) on the centres just computed: for every sphere group (= link) the most
     // penetrating pair against all LATER groups.  Lanes take the partners b of one sphere a at a time; the per-group
     // minimum is a 64-bit LDS atomicMin on (pen, a, b) -- the first minimal pair in (a, b) order, like a serial scan.
-    const int ng = min(h.NG - 1, 64);  // the last group has nothing after it
     sKey[lane] = ~0ull;
-    for (int sidx = lane; sidx < h.S; sidx += GQ_WAVE) {
-      sRad[sidx] = h.sphere[sidx * 4 + 3];
-    }
     __syncthreads();
     // four lanes per group (16 groups per pass): lane (g, q) scans the pairs (a in g) x (b = first later sphere + q,
     // + 4, ...), everything from LDS; the four partial minima of a group meet through two quad DPP steps on the
@@ -204,7 +243,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
       const int gi = g0 + (lane >> 2), q = lane & 3;
       unsigned long long key = ~0ull;
       if (gi < ng) {
-        const int a0 = h.group_off[gi], a1 = h.group_off[gi + 1];
+        const int a0 = g0 == 0 ? ga0 : h.group_off[gi], a1 = g0 == 0 ? ga1 : h.group_off[gi + 1];
         for (int a = a0; a < a1; ++a) {
           const gq3 pa = gq_mk(sC[a * 3], sC[a * 3 + 1], sC[a * 3 + 2]);
           const float ra = sRad[a];
@@ -292,6 +331,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   __shared__ float sI[GQ_FK_MAX_ITEMS * 6];
   __shared__ int sIn[GQ_FK_MAX_ITEMS];
   __shared__ float sNF[64 * 6];
+  __shared__ float sLT[64 * 12];   // link transforms of this row
+  __shared__ float sWr[64 * 6];    // link wrenches of this row
+  __shared__ int sLN[64];          // link -> node
+  __shared__ int sCh[64];          // child lists
   const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
   const float* hp = g.hand_pose + (size_t)row * g.D;
@@ -301,6 +344,24 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   const int n_c = (g.g_cpts || g.g_cnrm) ? g.n : 0;
   const int n_s = g.g_spheres ? h.S : 0;
   const int n_items = n_c + n_s;
+  // ---- everything that does not depend on another load is requested first (a single wavefront hides no latency) ----
+  for (int i = lane; i < h.L * 12; i += GQ_WAVE) sLT[i] = LT[i];
+  if (g.g_wrench)
+    for (int i = lane; i < h.L * 6; i += GQ_WAVE) sWr[i] = g.g_wrench[(size_t)row * h.L * 6 + i];
+  if (lane < h.L) sLN[lane] = h.link_node[lane];
+  int depth = -1, ch0 = 0, ch1 = 0, ntype = 0;
+  gq3 axj = gq_mk(0, 0, 0);
+  GqT Wj = gq_t_identity();
+  if (lane < h.J) {
+    depth = h.node_depth[lane];
+    ch0 = h.child_off[lane];
+    ch1 = h.child_off[lane + 1];
+    ntype = h.node_type[lane];
+    axj = gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]);
+    Wj = gq_t_load(W + lane * 12);
+  }
+  if (lane < h.child_off[h.J]) sCh[lane] = h.child_idx[lane];  // J - (number of roots) entries
+  __syncthreads();
   // ---- items: per-lane contribution to the global pose + (f, m) on the carrying node -----------------------------
   float acc[12];  // gt (3), gR (9) partial sums of this lane
 #pragma unroll
@@ -311,7 +372,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     if (it < n_c) {
       const int ci = (int)g.idx[(size_t)row * g.n + it];
       l = h.cand_link[ci];
-      const GqT T = gq_t_load(LT + l * 12);
+      const GqT T = gq_t_load(sLT + l * 12);
       const gq3 ph = gq_t_apply(T, gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
       const gq3 nh = gq_t_rot(T, gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]));
       if (g.g_cpts) {
@@ -338,7 +399,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
       l = h.sphere_link[sidx];
       const float* q = g.g_spheres + ((size_t)row * h.S + sidx) * 3;
       const gq3 gp = gq_mk(q[0], q[1], q[2]);
-      const GqT T = gq_t_load(LT + l * 12);
+      const GqT T = gq_t_load(sLT + l * 12);
       const gq3 ph = gq_t_apply(T, gq_mk(h.sphere[sidx * 4], h.sphere[sidx * 4 + 1], h.sphere[sidx * 4 + 2]));
       acc[0] += gp.x; acc[1] += gp.y; acc[2] += gp.z;
       acc[3] += gp.x * ph.x; acc[4] += gp.x * ph.y; acc[5] += gp.x * ph.z;
@@ -351,7 +412,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     if (it < GQ_FK_MAX_ITEMS) {
       sI[it * 6 + 0] = f.x; sI[it * 6 + 1] = f.y; sI[it * 6 + 2] = f.z;
       sI[it * 6 + 3] = m.x; sI[it * 6 + 4] = m.y; sI[it * 6 + 5] = m.z;
-      sIn[it] = h.link_node[l];
+      sIn[it] = sLN[l];
     }
   }
   __syncthreads();
@@ -360,10 +421,9 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   if (lane < h.J) {
     if (g.g_wrench) {
       for (int l = 0; l < h.L; ++l) {
-        if (h.link_node[l] != lane) continue;
-        const float* w = g.g_wrench + ((size_t)row * h.L + l) * 6;
+        if (sLN[l] != lane) continue;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) nf[k] += w[k];
+        for (int k = 0; k < 6; ++k) nf[k] += sWr[l * 6 + k];
       }
     }
     for (int it = 0; it < n_items; ++it) {
@@ -376,11 +436,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   }
   __syncthreads();
   // ---- fold children into parents, deepest level first ----------------------------------------------------------------
-  const int depth = (lane < h.J) ? h.node_depth[lane] : -1;
   for (int d = h.max_depth - 1; d >= 0; --d) {
     if (depth == d) {
-      for (int k = h.child_off[lane]; k < h.child_off[lane + 1]; ++k) {
-        const int c = h.child_idx[k];
+      for (int k = ch0; k < ch1; ++k) {
+        const int c = sCh[k];
 #pragma unroll
         for (int q = 0; q < 6; ++q) nf[q] += sNF[c * 6 + q];
       }
@@ -393,10 +452,9 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   float ej = 0.0f;
   if (lane < h.J) {  // d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
     const gq3 f = gq_mk(nf[0], nf[1], nf[2]), m = gq_mk(nf[3], nf[4], nf[5]);
-    const GqT Wj = gq_t_load(W + lane * 12);
-    const gq3 aw = gq_t_rot(Wj, gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]));
+    const gq3 aw = gq_t_rot(Wj, axj);
     const gq3 o = gq_t_pos(Wj);
-    float gth = (h.node_type[lane] == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
+    float gth = (ntype == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
     if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + lane];
     if (g.en.total) {  // E_joints = sum relu(theta - hi) + relu(lo - theta)  (energy.py:47-54)
       const float th = hp[9 + lane], hi = g.en.joints_upper[lane], lo = g.en.joints_lower[lane];

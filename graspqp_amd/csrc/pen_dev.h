@@ -175,6 +175,8 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
       for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
     } else {  // no room: rank the candidates here
       if (e < GQ_PG_ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
+      // the part of the item list this entry reserved but does not use must not be read as items
+      for (int i = ib; i < GQ_PG_ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
       const int f0 = g.off[l];
       float bd = GQ_INF_F;
       unsigned bo = 0xffffffffu;
@@ -205,6 +207,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
   for (int i = tid; i < n_item; i += 256) {
     const uint32_t it = s_item[i];
+    if (it == 0xffffffffu) continue;  // reserved by an entry that was ranked inline
     const int e = (int)(it >> 16);
     const GqPgEntry en = s_ent[e];
     const int f0 = g.off[en.link];

@@ -481,3 +481,69 @@ def test_config2_properties_and_determinism(gq):
     for k, i in (("E_dis", 0), ("E_pen", 2), ("E_spen", 3), ("E_joints", 4)):
         np.testing.assert_allclose(t2[k][rows].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
     np.testing.assert_allclose(t2["E_fc"][rows].cpu().numpy(), lo["E_fc"].detach().numpy(), rtol=0.3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other BASELINE configurations in small: shadow hand / 16 contacts (nz = 64), robotiq3 / 8-edge cones (nz = 96,
+# two QP columns per lane), several objects per process, and a batch large enough for the stand-alone stop-rule launch
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hand_name,n,k,n_obj,be", [("shadow_hand", 16, 4, 2, 40), ("robotiq3", 12, 8, 1, 24),
+                                                    ("allegro", 12, 4, 3, 100)])
+def test_stepper_other_configs(gq, hand_name, n, k, n_obj, be):
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    DEFAULT_W = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    spec = get_hand_spec(hand_name)
+    fvs = [meshes.superquadric(5 + i, n_u=32, n_v=16) for i in range(n_obj)]
+    sps = [meshes.surface_points(f, 600, oversample=4, seed=3 + i) for i, f in enumerate(fvs)]
+    B = n_obj * be
+    hand = gq.ops.HandHandle(spec)
+    ms = gq.ops.MeshSet(fvs)
+    hp = _rand_pose(spec, B, 31, spread=0.1).float().cuda()
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(2)).cuda()
+    fc_cfg = {"n_cone_vecs": k}
+    st = gq.stepper.GraspStepper(hand, ms, torch.tensor(np.stack(sps)), be, n, fc_cfg=fc_cfg, seed=5)
+    terms, total, grad = st.evaluate(hp, idx)
+    # (1) the fused launches == the autograd route built from the C-ABI building blocks
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=600)
+    om.initialize_from_meshes(fvs, surface_points_list=sps)
+    hpa = hp.clone().requires_grad_()
+    hm.set_parameters(hpa, idx)
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": k})
+    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=list(DEFAULT_W), svd_gain=0.1)
+    tot = sum(DEFAULT_W[kk] * v for kk, v in losses.items())
+    tot.sum().backward()
+    for kk in DEFAULT_W:
+        np.testing.assert_allclose(terms[kk].cpu().numpy(), losses[kk].detach().cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=kk)
+    np.testing.assert_allclose(total.cpu().numpy(), tot.detach().cpu().numpy(), rtol=2e-4)
+    ga, gg = hm.hand_pose.grad, grad
+    assert (ga - gg).norm() <= 2e-3 * gg.norm()
+    # (2) a sample of rows against the fp64 oracle (E_fc loosely: the oracle's stop rule sees 3 rows, the GPU all)
+    rows = [0, B // 2, B - 1]
+    oh = omodels.OracleHand(spec, torch.float64)
+    objs = [r // be for r in rows]
+    for r, o in zip(rows, objs):
+        oo = omodels.OracleObject([fvs[o]], [sps[o]], 1, torch.float64)
+        oh.set_parameters(hp[r : r + 1].cpu().double(), idx[r : r + 1].cpu())
+        lo = ref_cpu.calculate_energy(oh, oo, box_form=True, k=k)
+        for kk in ("E_dis", "E_pen", "E_spen", "E_joints"):
+            np.testing.assert_allclose(terms[kk][r].item(), lo[kk].item(), rtol=3e-4, atol=3e-6, err_msg=f"{kk} row {r}")
+        np.testing.assert_allclose(terms["E_fc"][r].item(), lo["E_fc"].item(), rtol=0.3)
+    # (3) iterations run (graph replay == eager), stay finite and are reproducible
+    outs = []
+    for rep in range(2):
+        s2 = gq.stepper.GraspStepper(hand, ms, torch.tensor(np.stack(sps)), be, n, fc_cfg=fc_cfg, seed=5)
+        s2.reset(hp, idx)
+        if rep == 1:
+            s2.capture(iters=2)
+        for _ in range(4):
+            s2.step()
+        s2.flush()
+        torch.cuda.synchronize()
+        outs.append((s2.energy.clone(), s2.hand_pose.clone(), s2.contact_idx.clone()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))

@@ -100,6 +100,8 @@ ProposeDesc = _struct("ProposeDesc", [
     ("step", "p"), ("step_size_out", "p"), ("g2_scratch", "p"), ("energy", "p"), ("batch_each", "l"), ("z_out", "p"), ("step_size", "f"),
     ("stepsize_period", "i"), ("decay", "f"), ("mu", "f"), ("switch_possibility", "f"), ("clip_grad", "i"),
     ("slot_ctr", "p"), ("slots", "i")])
+SdfDesc = _struct("SdfDesc", [("meshes", "p"), ("queries_per_mesh", "l"), ("dist_sq", "p"), ("sign", "p"),
+                              ("obj_dir", "p"), ("closest", "p")])
 AcceptDesc = _struct("AcceptDesc", [
     ("u_accept", "p"), ("z", "p"), ("reset_mask", "p"), ("step", "p"), ("starting_temperature", "f"), ("decay", "f"),
     ("annealing_period", "i"), ("energy", "p"), ("pose", "p"), ("idx", "p"), ("grad", "p"), ("accept", "p"),

@@ -6,6 +6,8 @@
 // products down a 16-24 joint tree, i.e. latency- not throughput-bound; the per-row scratch (node transforms,
 // node wrenches) lives in a caller-provided workspace so nothing is dynamically indexed in registers.
 #include "loop_dev.h"
+#include "sdf_dev.h"
+#include "wave.h"
 
 struct gqHand {
   int J, L, C, S, NG, max_depth;
@@ -107,6 +109,8 @@ struct GqFkArgs {
   float spen_scale;
   int has_propose;   // MalaStar.try_step runs first in the same wavefront and WRITES hand_pose / idx
   GqProposeArgs pr;
+  int has_sdf;       // the contact queries of the row are answered in the same launch
+  GqWaveArgs sdf;
 };
 
 // order-preserving map of floats onto unsigned (and back)
@@ -119,13 +123,11 @@ __device__ __forceinline__ float gq_o2f(unsigned o) {
 }
 
 // one wavefront per row: lane j owns joint node j, then link j, then contacts / spheres j, j+64, ...
-__global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
-  __shared__ float sW[64 * 12];
-  __shared__ float sT[64 * 12];
-  __shared__ float sC[256 * 3];             // world sphere centres (self penetration)
-  __shared__ unsigned long long sKey[64];   // per sphere group: (pen, a, b) of the most penetrating pair
-  __shared__ float sRad[256];
-  const int row = blockIdx.x, lane = gq_lane();
+// One wavefront does the kinematics of the row (the barriers below are wavefront-level: blocks of this kernel are either
+// a single wavefront, or -- with the object SDF attached -- wavefront 0 plus query wavefronts that wait at the one
+// block barrier further down).
+__device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, int lane, float* sW, float* sT, float* sC,
+                                                  unsigned long long* sKey, float* sRad, float* sCP) {
   const gqHand& h = g.h;
   // The constant hand tables this lane needs (its joint node, its link, its first sphere, its sphere group) are loaded
   // BEFORE anything else: a single wavefront per row hides no latency, and the barriers / fences below would otherwise
@@ -178,13 +180,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
     A = gq_t_mul(pre, gq_joint_motion(ntype, ax, hp[9 + lane]));
     if (parent < 0) gq_t_store(sW + lane * 12, A);
   }
-  __syncthreads();
+  gq_wave_sync();
   for (int d = 1; d <= h.max_depth; ++d) {  // level by level down the tree
     if (depth == d) {
       A = gq_t_mul(gq_t_load(sW + parent * 12), A);
       gq_t_store(sW + lane * 12, A);
     }
-    __syncthreads();
+    gq_wave_sync();
   }
   if (lane < h.J) gq_t_store(g.node_W + ((size_t)row * h.J + lane) * 12, A);
   if (lane < h.L) {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
     gq_t_store(sT + lane * 12, T);
     gq_t_store(g.link_T + ((size_t)row * h.L + lane) * 12, T);
   }
-  __syncthreads();
+  gq_wave_sync();
   for (int c = lane; c < g.n; c += GQ_WAVE) {
     int cl = cl0;
     gq3 cp = cp0, cn = cn0;
@@ -208,6 +210,9 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
     const gq3 nw = gq_mv(R, gq_t_rot(T, cn));
     float* o = g.cpts + ((size_t)row * g.n + c) * 3;
     o[0] = pw.x; o[1] = pw.y; o[2] = pw.z;
+    if (sCP && c < GQ_WAVE) {
+      sCP[c * 3] = pw.x; sCP[c * 3 + 1] = pw.y; sCP[c * 3 + 2] = pw.z;
+    }
     o = g.cnrm + ((size_t)row * g.n + c) * 3;
     o[0] = nw.x; o[1] = nw.y; o[2] = nw.z;
   }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
     // penetrating pair against all LATER groups.  Lanes take the partners b of one sphere a at a time; the per-group
     // minimum is a 64-bit LDS atomicMin on (pen, a, b) -- the first minimal pair in (a, b) order, like a serial scan.
     sKey[lane] = ~0ull;
-    __syncthreads();
+    gq_wave_sync();
     // four lanes per group (16 groups per pass): lane (g, q) scans the pairs (a in g) x (b = first later sphere + q,
     // + 4, ...), everything from LDS; the four partial minima of a group meet through two quad DPP steps on the
     // (pen, a, b) key, whose order is the serial scan's order.
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
       }
       if (gi < ng && q == 0) sKey[gi] = key;
     }
-    __syncthreads();
+    gq_wave_sync();
     // energy: fixed DPP tree over the groups; gradient: lane s collects, in group order, what lands on sphere s
     float e = 0.0f;
     if (lane < ng) {
@@ -293,6 +298,32 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_kernel(GqFkArgs g) {
       float* o = g.g_spheres + ((size_t)row * h.S + sidx) * 3;
       o[0] = acc.x; o[1] = acc.y; o[2] = acc.z;
     }
+  }
+}
+
+// block = one row.  has_sdf: blockDim = 64 * (number of query wavefronts); after the kinematics every wavefront answers
+// contact queries c = wave, wave + nw, ... of the row against the row's object mesh (gq_sdf_wave_query).
+__global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
+  __shared__ float sW[64 * 12];
+  __shared__ float sT[64 * 12];
+  __shared__ float sC[256 * 3];             // world sphere centres (self penetration)
+  __shared__ unsigned long long sKey[64];   // per sphere group: (pen, a, b) of the most penetrating pair
+  __shared__ float sRad[256];
+  __shared__ float sCP[GQ_WAVE * 3];        // world contact points handed to the query wavefronts
+  const int row = blockIdx.x, lane = gq_lane(), wv = (int)threadIdx.x / GQ_WAVE;
+  if (wv == 0) gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, g.has_sdf ? sCP : nullptr);
+  if (!g.has_sdf) return;
+  __syncthreads();
+  const int nw = (int)blockDim.x / GQ_WAVE;
+  for (int c = wv; c < g.n; c += nw) {
+    gq3 p;
+    if (c < GQ_WAVE) {
+      p = gq_mk(sCP[c * 3], sCP[c * 3 + 1], sCP[c * 3 + 2]);
+    } else {  // more than 64 contacts: written to global memory by wavefront 0 before the barrier
+      const float* q = g.cpts + ((size_t)row * g.n + c) * 3;
+      p = gq_mk(q[0], q[1], q[2]);
+    }
+    gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + c, p, lane);
   }
 }
 
@@ -603,6 +634,8 @@ static int gq_upload(T** dst, const T* src, size_t n) {
 }
 
 int gq_colsq_launch_(const float* grad, int B, int D, int clip, float* g2, void* stream);  // loop.hip
+int gq_sdf_wave_args_(const gqMeshSet* ms, int64_t n_points, int64_t queries_per_mesh, float* dist_sq, int32_t* sign,
+                      float* normal, float* closest, GqWaveArgs* out);  // sdf.hip
 
 extern "C" {
 
@@ -701,7 +734,7 @@ int gq_fk_workspace_bytes(const gqHand* h, int64_t batch, size_t* bytes) {
 int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contact_idx, int64_t batch, int n_contact,
                   float* Rg, float* link_T, float* contact_points, float* contact_normals, float* sphere_centers,
                   float spen_scale, float* e_spen, float* g_sphere_centers, const gqProposeDesc* propose,
-                  void* workspace, size_t workspace_bytes, void* stream) {
+                  const gqSdfDesc* sdf, void* workspace, size_t workspace_bytes, void* stream) {
   GQ_REQUIRE(h && hand_pose && Rg && link_T && workspace, "fk_forward: null pointer");
   GQ_REQUIRE(!e_spen || (sphere_centers && g_sphere_centers && h->S > 0 && h->S <= 256),
              "fk_forward: the fused self-penetration term needs sphere_centers and g_sphere_centers");
@@ -762,7 +795,17 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
     int rc = gq_colsq_launch_(propose->grad, (int)batch, a.D, propose->clip_grad, propose->g2_scratch, stream);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
+  int nw = 1;
+  if (sdf) {  // the contact queries of a row are answered by the row's block: up to 12 query wavefronts
+    GQ_REQUIRE(n_contact > 0 && contact_points, "fk_forward: gqSdfDesc needs contact points");
+    int rc = gq_sdf_wave_args_(sdf->meshes, batch * n_contact, sdf->queries_per_mesh, sdf->dist_sq, sdf->sign,
+                               sdf->obj_dir, sdf->closest, &a.sdf);
+    if (rc) return rc;
+    a.has_sdf = 1;
+    const int rounds = (n_contact + 11) / 12;
+    nw = (n_contact + rounds - 1) / rounds;
+  }
+  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE * nw), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -21,169 +21,12 @@ __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t*
   rec[i] = gq_make_face(gq_mk(v[0], v[1], v[2]), gq_mk(v[3], v[4], v[5]), gq_mk(v[6], v[7], v[8]), (int)src);
 }
 
-// ---- wave per query -------------------------------------------------------------------------------------------
-// queries are grouped: query q uses mesh (q / queries_per_mesh); mesh m's records are rec[off[m] .. off[m+1]).
-// With a mesh set the faces of every mesh are Morton-sorted and grouped in clusters of 64 (one face per lane) with an
-// AABB each: the wave first evaluates the cluster whose box is nearest to the query, then visits only clusters whose
-// box is not farther than the best distance found so far -- an exact search (lower bound vs. running minimum).
-struct GqWaveArgs {
-  const float* points;
-  int64_t N;
-  const GqFace* rec;
-  const int32_t* off;      // (n_mesh+1) or null (single soup of single_F faces, no clusters)
-  const float* cl_aabb;    // (n_cl64, 16) oriented cluster boxes (gq_cluster_bound) or null
-  const int32_t* cl_off;   // (n_mesh+1) first 64-cluster of each mesh
-  int single_F;
-  int64_t queries_per_mesh;
-  unsigned long long* dbg;  // diagnostics (gq_debug_set_pen_counters): [0] += cluster visits, [1] += queries
-  float* dist_sq;
-  int32_t* sign;
-  float* normal;
-  float* closest;
-};
-
-// lower bound of the squared distance from p to any face of a cluster (oriented box of gq_cluster_bound)
-__device__ __forceinline__ float gq_cluster_lb(const float* __restrict__ r, gq3 p) {
-  const float4 c = *reinterpret_cast<const float4*>(r), u = *reinterpret_cast<const float4*>(r + 4),
-               v = *reinterpret_cast<const float4*>(r + 8), n = *reinterpret_cast<const float4*>(r + 12);
-  const gq3 d = gq_mk(p.x - c.x, p.y - c.y, p.z - c.z);
-  const float eu = fmaxf(fabsf(fmaf(d.x, u.x, fmaf(d.y, u.y, d.z * u.z))) - c.w, 0.0f);
-  const float ev = fmaxf(fabsf(fmaf(d.x, v.x, fmaf(d.y, v.y, d.z * v.z))) - u.w, 0.0f);
-  const float en = fmaxf(fabsf(fmaf(d.x, n.x, fmaf(d.y, n.y, d.z * n.z))) - v.w, 0.0f);
-  return fmaf(eu, eu, fmaf(ev, ev, en * en));
-}
-
-__device__ __forceinline__ void gq_wave_eval_cluster(const GqFace* __restrict__ rec, int f, int f1, gq3 p, float& best,
-                                                     unsigned& borig, int& bi) {
-  if (f < f1) {
-    const GqFace fc = rec[f];
-    const gq3 d = p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z);
-    const float d2 = gq_tri_rank(fc, d);
-    const unsigned orig = (unsigned)__float_as_int(fc.r5.z);
-    if (d2 < best || (d2 == best && orig < borig)) {
-      best = d2;
-      borig = orig;
-      bi = f;
-    }
-  }
-}
+#include "sdf_dev.h"
 
 __global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
   if (q >= g.N) return;
-  const int lane = gq_lane();
-  const int mesh = (int)(q / g.queries_per_mesh);
-  const int f0 = g.off ? g.off[mesh] : 0, f1 = g.off ? g.off[mesh + 1] : g.single_F;
-  const gq3 p = gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]);
-  float best = GQ_INF_F;
-  unsigned borig = 0xffffffffu;
-  int bi = -1;
-  if (g.cl_aabb == nullptr) {
-    for (int f = f0 + lane; f < f1; f += GQ_WAVE) gq_wave_eval_cluster(g.rec, f, f1, p, best, borig, bi);
-  } else {
-    const int c0 = g.cl_off[mesh], nC = g.cl_off[mesh + 1] - c0;
-    // Best-first over the 64-face clusters: lane l keeps the lower bounds of clusters cb + l, cb + 64 + l, ... in
-    // registers.  Each round takes the (up to) GQ_TOPK unvisited clusters with the smallest bounds that can still beat
-    // the best distance found, loads their faces together (one face per lane and cluster -- the GQ_TOPK record loads
-    // are in flight at once, which is what matters: a round is one L2 round trip) and evaluates them.  It stops as
-    // soon as the smallest remaining bound exceeds the best distance: for a point at distance d only clusters whose
-    // box intersects the ball of radius d are ever touched.
-    constexpr int KC = 4;  // 256 clusters (16384 faces) per pass
-    constexpr int GQ_TOPK = 4;
-    float ub = GQ_INF_F;
-    int visits = 0;
-    for (int cb = 0; cb < nC; cb += KC * GQ_WAVE) {
-      float lb[KC];
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        const int c = cb + k * GQ_WAVE + lane;
-        lb[k] = (c < nC) ? gq_cluster_lb(g.cl_aabb + (size_t)(c0 + c) * 16, p) * 0.9999f : GQ_INF_F;
-      }
-      for (;;) {
-        int pick[GQ_TOPK];
-#pragma unroll
-        for (int j = 0; j < GQ_TOPK; ++j) {
-          float m = lb[0];
-          int mk = 0;
-#pragma unroll
-          for (int k = 1; k < KC; ++k) {
-            if (lb[k] < m) {
-              m = lb[k];
-              mk = k;
-            }
-          }
-          const float mw = gq_dpp_min(m);
-          pick[j] = -1;
-          if (mw <= ub) {  // wave-uniform; false when everything is visited (inf) or NaN
-            const unsigned long long who = __ballot(m == mw);
-            const int src = __ffsll((long long)who) - 1;
-            pick[j] = cb + gq_readlane_i(mk, src) * GQ_WAVE + src;
-            if (lane == src) {
-#pragma unroll
-              for (int k = 0; k < KC; ++k)
-                if (k == mk) lb[k] = GQ_INF_F;
-            }
-          }
-        }
-        if (pick[0] < 0) break;
-        GqFace fc[GQ_TOPK];
-#pragma unroll
-        for (int j = 0; j < GQ_TOPK; ++j) {
-          const int f = f0 + pick[j] * 64 + lane;
-          if (pick[j] >= 0 && f < f1) fc[j] = g.rec[f];
-        }
-#pragma unroll
-        for (int j = 0; j < GQ_TOPK; ++j) {
-          const int f = f0 + pick[j] * 64 + lane;
-          if (pick[j] >= 0 && f < f1) {
-            const gq3 d = p - gq_mk(fc[j].r0.x, fc[j].r0.y, fc[j].r0.z);
-            const float d2 = gq_tri_rank(fc[j], d);
-            const unsigned orig = (unsigned)__float_as_int(fc[j].r5.z);
-            if (d2 < best || (d2 == best && orig < borig)) {
-              best = d2;
-              borig = orig;
-              bi = f;
-            }
-          }
-          visits += pick[j] >= 0;
-        }
-        ub = gq_dpp_min(best);
-      }
-    }
-    if (g.dbg && lane == 0) {
-      atomicAdd(&g.dbg[0], (unsigned long long)visits);
-      atomicAdd(&g.dbg[1], 1ull);
-      atomicMax(&g.dbg[2], (unsigned long long)visits);
-      if (visits > 16) atomicAdd(&g.dbg[3], 1ull);
-    }
-  }
-  // winner = smallest distance, then smallest original face index (two DPP min passes)
-  const float dmin = gq_dpp_min(best);
-  const bool tie = (best == dmin) && (bi >= 0);
-  const float omin = gq_dpp_min(tie ? (float)borig : GQ_INF_F);  // face indices < 2^24 are exact in fp32
-  const unsigned long long win = __ballot(tie && (float)borig == omin);
-  const int face = win ? gq_readlane_i(bi, __ffsll((long long)win) - 1) : -1;
-  if (lane == 0) {
-    GqSdfOut o;
-    if (face >= f0 && face < f1) {
-      o = gq_tri_finish(g.rec[face], p);
-    } else {  // empty mesh or all-NaN distances
-      o.dist2 = GQ_INF_F;
-      o.sign = 1;
-      o.normal = gq_mk(0, 0, 0);
-      o.closest = p;
-    }
-    g.dist_sq[q] = o.dist2;
-    g.sign[q] = o.sign;
-    if (g.normal) {
-      g.normal[q * 3 + 0] = o.normal.x;
-      g.normal[q * 3 + 1] = o.normal.y;
-      g.normal[q * 3 + 2] = o.normal.z;
-    }
-    g.closest[q * 3 + 0] = o.closest.x;
-    g.closest[q * 3 + 1] = o.closest.y;
-    g.closest[q * 3 + 2] = o.closest.z;
-  }
+  gq_sdf_wave_query(g, q, gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]), gq_lane());
 }
 
 // ---- point per lane -----------------------------------------------------------------------------------------------
@@ -752,6 +595,29 @@ static void gq_cluster_bound(const float* fv, const int32_t* perm, int64_t a, in
   out16[15] = 0.0f;
 }
 
+// internal (kin.hip): argument block of the wave-per-query kernel for a mesh set; `points` is left to the caller
+int gq_sdf_wave_args_(const gqMeshSet* ms, int64_t n_points, int64_t queries_per_mesh, float* dist_sq, int32_t* sign,
+                      float* normal, float* closest, GqWaveArgs* out) {
+  GQ_REQUIRE(ms && dist_sq && sign && closest && out, "sdf_forward_meshset: null pointer");
+  GQ_REQUIRE(queries_per_mesh > 0 && n_points == queries_per_mesh * ms->n_mesh,
+             "sdf_forward_meshset: n_points=%lld != queries_per_mesh=%lld * n_mesh=%d", (long long)n_points,
+             (long long)queries_per_mesh, ms->n_mesh);
+  GqWaveArgs w{};
+  w.N = n_points;
+  w.rec = ms->rec;
+  w.off = ms->off_dev;
+  w.cl_aabb = ms->cl_aabb_dev;
+  w.cl_off = ms->cl_off_dev;
+  w.queries_per_mesh = queries_per_mesh;
+  w.dbg = gq_pen_dbg_;
+  w.dist_sq = dist_sq;
+  w.sign = sign;
+  w.normal = normal;
+  w.closest = closest;
+  *out = w;
+  return GQ_OK;
+}
+
 extern "C" {
 
 // diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
@@ -969,23 +835,11 @@ int gq_sdf_forward(const float* points, int64_t n_points, const float* face_vert
 int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_points, int64_t queries_per_mesh,
                            float* dist_sq, int32_t* sign, float* normal, float* closest, void* stream) {
   if (n_points == 0) return GQ_OK;
-  GQ_REQUIRE(ms && points && dist_sq && sign && closest, "sdf_forward_meshset: null pointer");
-  GQ_REQUIRE(queries_per_mesh > 0 && n_points == queries_per_mesh * ms->n_mesh,
-             "sdf_forward_meshset: n_points=%lld != queries_per_mesh=%lld * n_mesh=%d", (long long)n_points,
-             (long long)queries_per_mesh, ms->n_mesh);
+  GQ_REQUIRE(points, "sdf_forward_meshset: null pointer");
   GqWaveArgs w{};
+  int rc = gq_sdf_wave_args_(ms, n_points, queries_per_mesh, dist_sq, sign, normal, closest, &w);
+  if (rc) return rc;
   w.points = points;
-  w.N = n_points;
-  w.rec = ms->rec;
-  w.off = ms->off_dev;
-  w.cl_aabb = ms->cl_aabb_dev;
-  w.cl_off = ms->cl_off_dev;
-  w.queries_per_mesh = queries_per_mesh;
-  w.dbg = gq_pen_dbg_;
-  w.dist_sq = dist_sq;
-  w.sign = sign;
-  w.normal = normal;
-  w.closest = closest;
   hipLaunchKernelGGL(gq_sdf_wave_kernel, dim3((unsigned)((n_points + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w);
   GQ_LAUNCH_CHECK();
   return GQ_OK;

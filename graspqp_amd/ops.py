@@ -358,7 +358,7 @@ class _FK(torch.autograd.Function):
         sc = torch.empty(B, max(hand.S, 1), 3, device=dev)
         ws, nb = hand.fk_ws(B, dev)
         _C.call("gq_fk_forward", hand.handle, _C.f32(hp), _C.i64(ix), B, n, _C.f32(Rg), _C.f32(LT), _C.f32(cp),
-                _C.f32(cn), _C.f32(sc) if hand.S > 0 else None, 0.0, None, None, None, _C.ptr(ws), nb, _C.stream_ptr())
+                _C.f32(cn), _C.f32(sc) if hand.S > 0 else None, 0.0, None, None, None, None, _C.ptr(ws), nb, _C.stream_ptr())
         ctx.save_for_backward(hp, ix, Rg, LT, ws)
         ctx.hand = hand
         ctx.nb = nb

@@ -148,18 +148,22 @@ class GraspStepper:
         ac.n_terms, ac.terms_new, ac.terms = 5, self.terms_new.data_ptr(), self.terms.data_ptr()
         ac.slot_ctr, ac.slots = self._slot_ctr.data_ptr(), 64
         self._propose_desc, self._accept_desc = pr, ac
+        sd = _C.SdfDesc()
+        sd.meshes, sd.queries_per_mesh = self.objs.handle, self.be * n
+        sd.dist_sq, sd.sign, sd.obj_dir, sd.closest = (t.data_ptr() for t in (self.d2, self.sgn, self.onrm, self.closest))
+        self._sdf_desc = sd
 
     # ---- energy + gradient of the pose in (pose, idx) -> terms_new (5,B), total_new (B), grad_new (B,D) ----------
     # Four pieces: FK (+ self penetration), then two independent branches (contacts -> object SDF -> E_fc fwd+bwd |
     # hand penetration fwd+bwd), then FK backward with the row energies.  ``_evaluate`` runs the branches on two
     # streams when ``fork`` is set (inside a hipGraph capture they become parallel graph branches).
-    def _eval_fk(self, pose, idx, st, loop=False):
+    def _eval_fk(self, pose, idx, st, loop=False, sdf=False):
         B, n = self.B, self.n
         _C.call("gq_fk_forward", self.hand.handle, _C.f32(pose), _C.i64(idx), B, n, _C.f32(self.Rg), _C.f32(self.link_T),
                 _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None,
                 float(self.w["E_spen"]), _C.f32(self.terms_new[3]) if self.S > 0 else None,
                 _C.f32(self.g_sph_w) if self.S > 0 else None, ctypes.byref(self._propose_desc) if loop else None,
-                _C.ptr(self.fk_ws), self.fk_nb, st)
+                ctypes.byref(self._sdf_desc) if sdf else None, _C.ptr(self.fk_ws), self.fk_nb, st)
         if self.S == 0:
             _C.call("gq_fill", _C.f32(self.terms_new[3]), 0.0, self.B, st)
 
@@ -200,11 +204,9 @@ class GraspStepper:
     def _evaluate(self, pose, idx, st, fork=False, timer=None, fused=False, loop=False):
         """loop=True: one whole MALA* iteration -- the proposal is the head of the FK forward kernel (pose / idx are its
         outputs), the accept step the tail of the FK backward kernel."""
-        self._eval_fk(pose, idx, st, loop)
+        self._eval_fk(pose, idx, st, loop, sdf=fused)
         if fused:
-            # object SDF of the contacts, then both branches side by side in two launches
-            _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,
-                    _C.f32(self.d2), _C.i32(self.sgn), _C.f32(self.onrm), _C.f32(self.closest), st)
+            # (the object SDF of the contacts rode along with the kinematics) both branches side by side in two launches
             self._pen_desc.hand_pose = pose.data_ptr()
             _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
         elif not fork:

@@ -159,6 +159,12 @@ typedef struct gqProposeDesc {
   float step_size; int32_t stepsize_period; float decay, mu, switch_possibility; int32_t clip_grad;
   int32_t* slot_ctr; int32_t slots;
 } gqProposeDesc;
+/* Optional: the object SDF of the row's contact points (gq_sdf_forward_meshset on contact_points, queries_per_mesh =
+ * batch_size * n_contact) answered in the same launch by extra wavefronts of the row's block.                   */
+typedef struct gqSdfDesc {
+  const gqMeshSet* meshes; int64_t queries_per_mesh;
+  float* dist_sq; int32_t* sign; float* obj_dir; float* closest;
+} gqSdfDesc;
 typedef struct gqAcceptDesc {
   const float* u_accept; const float* z; const uint8_t* reset_mask; const int64_t* step;
   float starting_temperature, decay; int32_t annealing_period;
@@ -173,6 +179,7 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
                   float spen_scale, float* e_spen /* (B) or NULL: gq_self_pen_forward fused in */,
                   float* g_sphere_centers /* (B,S,3), with e_spen: spen_scale * dE_spen/dcentre */,
                   const gqProposeDesc* propose /* NULL, or: hand_pose / contact_idx are first WRITTEN by the proposal */,
+                  const gqSdfDesc* sdf /* NULL, or the object SDF of the contact points in the same launch */,
                   void* workspace, size_t workspace_bytes, void* stream);
 /* Optional tail of gq_fk_backward: E_dis, E_joints (with its gradient) and the weighted total of one row
  * (core/energy.py:25-28,47-54; scripts/fit.py:434-438), so the iteration needs no separate reduction launch.     */

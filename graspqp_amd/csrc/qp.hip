@@ -131,6 +131,84 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* _
   }
 }
 
+// same rule for up to 4096 rows: 1024 threads, RPT rows per thread, both tables in registers after ONE round of loads,
+// then per iteration a DPP reduction per wavefront and a 16-entry LDS exchange.
+template <int RPT>
+__global__ __launch_bounds__(1024) void gq_qp_stop_block_kernel(const float* __restrict__ resid,
+                                                                const float* __restrict__ mu, int B, int max_iter,
+                                                                float eps, int not_improved_lim, int* __restrict__ kstar,
+                                                                int* __restrict__ n_iter_out) {
+  __shared__ float s_mx[2][16], s_mn[2][16];
+  __shared__ int s_any[2][16];
+  const int tid = threadIdx.x, lane = gq_lane(), wv = tid / GQ_WAVE;
+  float rs[RPT][GQ_STOP_MAXIT], mt[GQ_STOP_MAXIT];  // mt[it] = min of mu over this thread's rows (only the min is used)
+#pragma unroll
+  for (int it = 0; it < GQ_STOP_MAXIT; ++it) mt[it] = GQ_INF;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int r = tid + 1024 * k;
+#pragma unroll
+    for (int it = 0; it < GQ_STOP_MAXIT; ++it) {
+      const bool ok = r < B && it < max_iter;
+      rs[k][it] = ok ? resid[(size_t)r * max_iter + it] : 0.0f;
+      if (ok) mt[it] = gq_nanmin(mt[it], mu[(size_t)r * max_iter + it]);
+    }
+  }
+  float run[RPT];
+  int not_improved = 0, stop_at = max_iter - 1;
+  bool done = false;
+#pragma unroll
+  for (int it = 0; it < GQ_STOP_MAXIT; ++it) {
+    if (it < max_iter && !done) {  // block-uniform
+      float mx = -GQ_INF, mn = GQ_INF;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        if (tid + 1024 * k < B) {
+          float bst = rs[k][it];
+          if (it > 0) {
+            bst = run[k];
+            if (rs[k][it] < bst) {
+              bst = rs[k][it];
+              any = true;
+            }
+          }
+          run[k] = bst;
+          mx = gq_nanmax(mx, bst);
+        }
+      }
+      mn = mt[it];
+      const bool any_w = __ballot(any) != 0ull;
+      const float mxw = -gq_dpp_nanmin(-mx), mnw = gq_dpp_nanmin(mn);
+      const int par = it & 1;  // double-buffered exchange: one barrier per iteration
+      if (lane == 0) {
+        s_mx[par][wv] = mxw;
+        s_mn[par][wv] = mnw;
+        s_any[par][wv] = any_w ? 1 : 0;
+      }
+      __syncthreads();
+      float bmx = -GQ_INF, bmn = GQ_INF;
+      int bany = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        bmx = gq_nanmax(bmx, s_mx[par][w]);
+        bmn = gq_nanmin(bmn, s_mn[par][w]);
+        bany |= s_any[par][w];
+      }
+      not_improved = (it == 0) ? 0 : (bany ? 0 : not_improved + 1);
+      if ((not_improved == not_improved_lim) || (bmx < eps) || (bmn > 1e32f)) {
+        stop_at = it;
+        done = true;
+      }
+    }
+  }
+  if (tid == 0) {
+    kstar[0] = stop_at;
+    kstar[1] = stop_at + 1;
+    if (n_iter_out) *n_iter_out = stop_at + 1;
+  }
+}
+
 __global__ __launch_bounds__(GQ_WAVE) void gq_qp_select_kernel(const float* __restrict__ resid,
                                                                const float* __restrict__ snap,
                                                                const int* __restrict__ kstar, int B, int nz,
@@ -186,6 +264,22 @@ static GqQpWs gq_qp_carve(void* base, int B, int nz, int max_iter) {
   return w;
 }
 
+static void gq_qp_stop_dispatch(const float* resid, const float* mu, int B, int max_iter, float eps, int lim,
+                                float* runmin, int* kstar, int32_t* n_iter, hipStream_t st) {
+  if (B <= GQ_STOP_MAXB && max_iter <= GQ_STOP_MAXIT)
+    hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, resid, mu, B, max_iter, eps, lim, runmin,
+                       kstar, n_iter);
+  else if (B <= 2048 && max_iter <= GQ_STOP_MAXIT)
+    hipLaunchKernelGGL((gq_qp_stop_block_kernel<2>), dim3(1), dim3(1024), 0, st, resid, mu, B, max_iter, eps, lim, kstar,
+                       n_iter);
+  else if (B <= 4096 && max_iter <= GQ_STOP_MAXIT)
+    hipLaunchKernelGGL((gq_qp_stop_block_kernel<4>), dim3(1), dim3(1024), 0, st, resid, mu, B, max_iter, eps, lim, kstar,
+                       n_iter);
+  else
+    hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, resid, mu, B, max_iter, eps, lim, runmin, kstar,
+                       n_iter);
+}
+
 static int gq_launch_iter(const GqQpArgs& a, int mode, hipStream_t st) {
   if (mode == 0) return gq_qp_lr_launch_iter(a, st);
   if (a.nz <= 16) return gq_qp_launch_iter_16(a, mode, st);
@@ -215,12 +309,7 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
   a.snap = w.snap;
   int rc = gq_launch_iter(a, mode, st);
   if (rc) return rc;
-  if (a.B <= GQ_STOP_MAXB && a.max_iter <= GQ_STOP_MAXIT)
-    hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
-                       not_improved_lim, w.runmin, w.kstar, n_iter);
-  else
-    hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, w.resid, w.mu, a.B, a.max_iter, eps,
-                       not_improved_lim, w.runmin, w.kstar, n_iter);
+  gq_qp_stop_dispatch(w.resid, w.mu, a.B, a.max_iter, eps, not_improved_lim, w.runmin, w.kstar, n_iter, st);
   GQ_LAUNCH_CHECK();
   if (x == nullptr) return GQ_OK;  // internal callers (fc.hip) select the best iterate inside their own kernel
   hipLaunchKernelGGL(gq_qp_select_kernel, dim3(a.B), dim3(GQ_WAVE), 0, st, w.resid, w.snap, w.kstar, a.B, a.nz,
@@ -244,13 +333,7 @@ int gq_qp_tables_(void* workspace, size_t workspace_bytes, int B, int nz, int ma
 }
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (B <= GQ_STOP_MAXB && max_iter <= GQ_STOP_MAXIT)
-    hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, resid, mu, B, max_iter, eps,
-                       not_improved_lim, runmin, kstar, n_iter);
-  else
-    hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, resid, mu, B, max_iter, eps, not_improved_lim,
-                       runmin, kstar, n_iter);
+  gq_qp_stop_dispatch(resid, mu, B, max_iter, eps, not_improved_lim, runmin, kstar, n_iter, (hipStream_t)stream);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -204,9 +204,15 @@ class GraspStepper:
     def _evaluate(self, pose, idx, st, fork=False, timer=None, fused=False, loop=False):
         """loop=True: one whole MALA* iteration -- the proposal is the head of the FK forward kernel (pose / idx are its
         outputs), the accept step the tail of the FK backward kernel."""
-        self._eval_fk(pose, idx, st, loop, sdf=fused)
+        # small batches: the contact queries ride along with the kinematics (latency); large ones: their own launch
+        # (throughput -- query wavefronts should not hold slots while wavefront 0 of their block does the kinematics)
+        attach = fused and self.B <= 512
+        self._eval_fk(pose, idx, st, loop, sdf=attach)
         if fused:
-            # (the object SDF of the contacts rode along with the kinematics) both branches side by side in two launches
+            if not attach:
+                _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,
+                        _C.f32(self.d2), _C.i32(self.sgn), _C.f32(self.onrm), _C.f32(self.closest), st)
+            # both branches side by side in two launches
             self._pen_desc.hand_pose = pose.data_ptr()
             _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
         elif not fork:

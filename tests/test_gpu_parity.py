@@ -150,6 +150,21 @@ def test_qp_iterate_matches_oracle(gq, golden_dir, n, k):
     assert ge < 2e-2, ge
 
 
+@pytest.mark.parametrize("B", [300, 1500, 3000, 5000])
+def test_qp_batch_global_stop_large_batches(gq, golden_dir, B):
+    """qpth's batch-global stop rule over large batches (the single-wavefront, 1024-thread and generic stop kernels):
+    the fixture's problems tiled to B rows must give every copy the solution of the un-tiled batch, because the rule
+    only looks at max / any / min over the rows."""
+    g = _load(golden_dir, "span_n4_k4.npz")
+    F = torch.tensor(g["F"], dtype=torch.float32).cuda()
+    b0 = F.shape[0]
+    x0 = gq.ops.lsq_box_qp(F, None, 1.0, 21.0)
+    rep = (B + b0 - 1) // b0
+    Fb = F.repeat(rep, 1, 1)[:B].contiguous()
+    xb = gq.ops.lsq_box_qp(Fb, None, 1.0, 21.0)
+    assert torch.equal(xb, x0.repeat(rep, 1)[:B])
+
+
 def test_qpfunction_level_boundary(gq):
     """QPFunction(Q, p, G, h) with G = [I; -I]; wrong G is refused loudly."""
     from graspqp_amd.metrics import QPFunction

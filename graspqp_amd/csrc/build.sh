@@ -9,12 +9,13 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 OBJS=()
 deps() {  # headers each translation unit includes
   case "$1" in
-    qp_lr|fcstep|stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h" ;;
+    qp_lr|fcstep) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h" ;;
+    stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h kin_dev.h" ;;
     qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
     sdf) echo "common.h tri.h pen_dev.h sdf_dev.h" ;;
     fc) echo "common.h fc_dev.h" ;;
     loop) echo "common.h fc_dev.h loop_dev.h" ;;
-    kin) echo "common.h loop_dev.h sdf_dev.h tri.h" ;;
+    kin) echo "common.h loop_dev.h sdf_dev.h tri.h kin_dev.h wave.h" ;;
     *) echo "common.h" ;;
   esac
 }

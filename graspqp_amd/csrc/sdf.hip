@@ -26,7 +26,9 @@ __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t*
 __global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
   if (q >= g.N) return;
-  gq_sdf_wave_query(g, q, gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]), gq_lane());
+  const int lane = gq_lane();
+  const GqSdfPre pre = gq_sdf_wave_prefetch(g, q, lane);
+  gq_sdf_wave_query(g, q, gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]), lane, pre);
 }
 
 // ---- point per lane -----------------------------------------------------------------------------------------------

@@ -50,17 +50,51 @@ __device__ __forceinline__ void gq_wave_eval_cluster(const GqFace* __restrict__ 
   }
 }
 
-// one wavefront answers query q at point p (all lanes pass the same q, p)
-__device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q, gq3 p, int lane) {
+// What a query can load before its point is known: mesh offsets and the oriented boxes of the first 256 clusters
+// (lane l: clusters l, l + 64, l + 128, l + 192).  In the FK forward kernel the query wavefronts fetch this while
+// wavefront 0 is still computing the contact points.
+struct GqSdfPre {
+  int f0, f1, c0, nC;
+  float4 box[4][4];
+};
+__device__ __forceinline__ GqSdfPre gq_sdf_wave_prefetch(const GqWaveArgs& g, int64_t q, int lane) {
+  GqSdfPre s;
   const int mesh = (int)(q / g.queries_per_mesh);
-  const int f0 = g.off ? g.off[mesh] : 0, f1 = g.off ? g.off[mesh + 1] : g.single_F;
+  s.f0 = g.off ? g.off[mesh] : 0;
+  s.f1 = g.off ? g.off[mesh + 1] : g.single_F;
+  s.c0 = 0;
+  s.nC = 0;
+  if (g.cl_aabb) {
+    s.c0 = g.cl_off[mesh];
+    s.nC = g.cl_off[mesh + 1] - s.c0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * GQ_WAVE + lane;
+      const float4* r = reinterpret_cast<const float4*>(g.cl_aabb + (size_t)(s.c0 + (c < s.nC ? c : 0)) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s.box[k][j] = r[j];
+    }
+  }
+  return s;
+}
+__device__ __forceinline__ float gq_cluster_lb4(const float4 (&r)[4], gq3 p) {
+  const gq3 d = gq_mk(p.x - r[0].x, p.y - r[0].y, p.z - r[0].z);
+  const float eu = fmaxf(fabsf(fmaf(d.x, r[1].x, fmaf(d.y, r[1].y, d.z * r[1].z))) - r[0].w, 0.0f);
+  const float ev = fmaxf(fabsf(fmaf(d.x, r[2].x, fmaf(d.y, r[2].y, d.z * r[2].z))) - r[1].w, 0.0f);
+  const float en = fmaxf(fabsf(fmaf(d.x, r[3].x, fmaf(d.y, r[3].y, d.z * r[3].z))) - r[2].w, 0.0f);
+  return fmaf(eu, eu, fmaf(ev, ev, en * en));
+}
+
+// one wavefront answers query q at point p (all lanes pass the same q, p)
+__device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q, gq3 p, int lane, const GqSdfPre& pre) {
+  const int f0 = pre.f0, f1 = pre.f1;
   float best = GQ_INF_F;
   unsigned borig = 0xffffffffu;
   int bi = -1;
   if (g.cl_aabb == nullptr) {
     for (int f = f0 + lane; f < f1; f += GQ_WAVE) gq_wave_eval_cluster(g.rec, f, f1, p, best, borig, bi);
   } else {
-    const int c0 = g.cl_off[mesh], nC = g.cl_off[mesh + 1] - c0;
+    const int c0 = pre.c0, nC = pre.nC;
     // Best-first over the 64-face clusters: lane l keeps the lower bounds of clusters cb + l, cb + 64 + l, ... in
     // registers.  Each round takes the (up to) GQ_TOPK unvisited clusters with the smallest bounds that can still beat
     // the best distance found, loads their faces together (one face per lane and cluster -- the GQ_TOPK record loads
@@ -71,12 +105,17 @@ __device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q
     constexpr int GQ_TOPK = 4;
     float ub = GQ_INF_F;
     int visits = 0;
-    for (int cb = 0; cb < nC; cb += KC * GQ_WAVE) {
-      float lb[KC];
+    float lb[KC];
 #pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        const int c = cb + k * GQ_WAVE + lane;
-        lb[k] = (c < nC) ? gq_cluster_lb(g.cl_aabb + (size_t)(c0 + c) * 16, p) * 0.9999f : GQ_INF_F;
+    for (int k = 0; k < KC; ++k)  // first pass: the boxes fetched ahead of time (dead after this)
+      lb[k] = (k * GQ_WAVE + lane < nC) ? gq_cluster_lb4(pre.box[k], p) * 0.9999f : GQ_INF_F;
+    for (int cb = 0; cb < nC; cb += KC * GQ_WAVE) {
+      if (cb > 0) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+          const int c = cb + k * GQ_WAVE + lane;
+          lb[k] = (c < nC) ? gq_cluster_lb(g.cl_aabb + (size_t)(c0 + c) * 16, p) * 0.9999f : GQ_INF_F;
+        }
       }
       for (;;) {
         int pick[GQ_TOPK];

@@ -6,12 +6,14 @@
 //             blocks [B/4, .. + gx B) pen query penetration-only hand query of 256 surface points of one row
 //   stage B   blocks [0, B)          fc tail   stop rule + E_fc + QP backward + contact gradient (wave 0 only)
 //             blocks [B, 2B)         pen bwd   link wrenches + E_pen of one row
+//             blocks [2B, 2B + B/4)  spheres   world sphere centres + self penetration (optional; 4 rows per block)
 //
 // With B = 256 rows neither branch fills 256 CUs on its own (the QP is one wavefront per row), and separate streams
 // cost 20..100 us of cross-queue dependency latency per iteration on this platform; putting both roles in one grid gives
 // the overlap without any inter-queue hand-shake.  The bodies are the ones of fcstep.hip / sdf.hip (same arithmetic),
 // the long-running fc blocks come first so that they are resident from the start.
 #include "fcstep_dev.h"
+#include "kin_dev.h"
 #include "pen_dev.h"
 
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
@@ -31,10 +33,32 @@ __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenAr
   }
 }
 
+struct GqSpenRole {  // third role of stage B: sphere centres + self penetration of 4 rows per block (0 blocks = absent)
+  gqHand h;
+  GqSpenArgs sa;
+  const float* Rg;
+  const float* hand_pose;
+  const float* link_T;
+  int D;
+};
+
 template <int NC, int RPL>
-__global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBwdArgs p) {
+__global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBwdArgs p, GqSpenRole sp) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
+  if (b >= 2 * f.B) {
+    const int wv = (int)threadIdx.x / GQ_WAVE, row = (b - 2 * f.B) * 4 + wv;
+    if (row >= f.B) return;
+    const int S = sp.h.S;
+    char* base = gq_lds + (size_t)wv * ((size_t)S * 16 + 512);
+    unsigned long long* sKey = reinterpret_cast<unsigned long long*>(base);
+    float* sC = reinterpret_cast<float*>(base + 512);
+    float* sRad = sC + 3 * S;
+    const float* hp = sp.hand_pose + (size_t)row * sp.D;
+    gq_spheres_row(sp.h, sp.sa, sp.link_T + (size_t)row * sp.h.L * 12, sp.Rg + (size_t)row * 9, gq_mk(hp[0], hp[1], hp[2]),
+                   row, gq_lane(), sC, sKey, sRad);
+    return;
+  }
   if (b < f.B) {  // one row per block here: 2B blocks = two per CU at B = 256, every tail wavefront has a CU's L1 to itself
     if (threadIdx.x >= GQ_WAVE) return;
     gq_fc_tail_body<NC, RPL>(f, b, reinterpret_cast<float*>(gq_lds));
@@ -69,10 +93,27 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   if (rc) return rc;
   const int gx = (p.P + 255) / 256;
   const bool two = f.nz > GQ_WAVE;
+  GqSpenRole sp{};
+  int n_sp = 0;
+  if (pen->hand) {
+    GQ_REQUIRE(pen->e_spen && pen->g_sphere_centers && pen->hand->S > 0 && pen->hand->S <= 256,
+               "fc_pen_step: the self-penetration role needs e_spen, g_sphere_centers and 1..256 spheres");
+    sp.h = *pen->hand;
+    sp.sa.spheres = pen->sphere_centers;
+    sp.sa.e_spen = pen->e_spen;
+    sp.sa.g_spheres = pen->g_sphere_centers;
+    sp.sa.spen_scale = pen->w_spen;
+    sp.Rg = pen->Rg;
+    sp.hand_pose = pen->hand_pose;
+    sp.link_T = pen->link_T;
+    sp.D = pen->pose_dim;
+    n_sp = (f.B + 3) / 4;
+  }
   const int nfc = (f.B + 3) / 4;
   const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)4 * f.n * 6 * sizeof(float));
-  const size_t lds_b = std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float));
-  const dim3 grid_a((unsigned)(nfc + gx * p.B)), grid_b((unsigned)(2 * f.B)), block(256);
+  const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
+                                n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);
+  const dim3 grid_a((unsigned)(nfc + gx * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
   if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx, nfc);
   else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx, nfc);
   GQ_LAUNCH_CHECK();
@@ -82,11 +123,11 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
     if (rc) return rc;
   }
   if (two) {
-    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<2, 4>), grid_b, block, lds_b, st, f, pb);
-    else hipLaunchKernelGGL((gq_stage_b_kernel<2, 0>), grid_b, block, lds_b, st, f, pb);
+    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<2, 4>), grid_b, block, lds_b, st, f, pb, sp);
+    else hipLaunchKernelGGL((gq_stage_b_kernel<2, 0>), grid_b, block, lds_b, st, f, pb, sp);
   } else {
-    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<1, 4>), grid_b, block, lds_b, st, f, pb);
-    else hipLaunchKernelGGL((gq_stage_b_kernel<1, 0>), grid_b, block, lds_b, st, f, pb);
+    if (fused_stop) hipLaunchKernelGGL((gq_stage_b_kernel<1, 4>), grid_b, block, lds_b, st, f, pb, sp);
+    else hipLaunchKernelGGL((gq_stage_b_kernel<1, 0>), grid_b, block, lds_b, st, f, pb, sp);
   }
   GQ_LAUNCH_CHECK();
   return GQ_OK;

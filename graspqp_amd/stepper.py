@@ -126,6 +126,10 @@ class GraspStepper:
         pd.link_wrench, pd.gRt, pd.w_pen, pd.e_pen = (self.wrench.data_ptr(), self.gRt.data_ptr(), float(self.w["E_pen"]),
                                                       self.terms_new[2].data_ptr())
         pd.span, pd.span_acc = self._span.data_ptr(), self._span_acc.data_ptr()
+        if self.S > 0:  # sphere centres + self penetration as a third role of the second fused launch
+            pd.hand, pd.w_spen = self.hand.handle, float(self.w["E_spen"])
+            pd.e_spen, pd.g_sphere_centers, pd.sphere_centers = (self.terms_new[3].data_ptr(), self.g_sph_w.data_ptr(),
+                                                                  self.spheres.data_ptr())
         self._fc_desc, self._pen_desc = fd, pd
         # MalaStar.try_step / accept_step as head / tail of the FK kernels
         self._fuse_loop = True
@@ -157,12 +161,13 @@ class GraspStepper:
     # Four pieces: FK (+ self penetration), then two independent branches (contacts -> object SDF -> E_fc fwd+bwd |
     # hand penetration fwd+bwd), then FK backward with the row energies.  ``_evaluate`` runs the branches on two
     # streams when ``fork`` is set (inside a hipGraph capture they become parallel graph branches).
-    def _eval_fk(self, pose, idx, st, loop=False, sdf=False):
+    def _eval_fk(self, pose, idx, st, loop=False, sdf=False, spheres=True):
         B, n = self.B, self.n
+        sph = self.S > 0 and spheres  # the fused path computes spheres + self penetration in gq_fc_pen_step instead
         _C.call("gq_fk_forward", self.hand.handle, _C.f32(pose), _C.i64(idx), B, n, _C.f32(self.Rg), _C.f32(self.link_T),
-                _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if self.S > 0 else None,
-                float(self.w["E_spen"]), _C.f32(self.terms_new[3]) if self.S > 0 else None,
-                _C.f32(self.g_sph_w) if self.S > 0 else None, ctypes.byref(self._propose_desc) if loop else None,
+                _C.f32(self.cpts), _C.f32(self.cnrm), _C.f32(self.spheres) if sph else None,
+                float(self.w["E_spen"]), _C.f32(self.terms_new[3]) if sph else None,
+                _C.f32(self.g_sph_w) if sph else None, ctypes.byref(self._propose_desc) if loop else None,
                 ctypes.byref(self._sdf_desc) if sdf else None, _C.ptr(self.fk_ws), self.fk_nb, st)
         if self.S == 0:
             _C.call("gq_fill", _C.f32(self.terms_new[3]), 0.0, self.B, st)
@@ -207,7 +212,7 @@ class GraspStepper:
         # small batches: the contact queries ride along with the kinematics (latency); large ones: their own launch
         # (throughput -- query wavefronts should not hold slots while wavefront 0 of their block does the kinematics)
         attach = fused and self.B <= 512
-        self._eval_fk(pose, idx, st, loop, sdf=attach)
+        self._eval_fk(pose, idx, st, loop, sdf=attach, spheres=not fused)
         if fused:
             if not attach:
                 _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,

@@ -103,6 +103,7 @@ int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, 
  * until gq_fk_backward, neither fills the GPU on its own at batch 256, and one grid holding both roles overlaps them
  * without a cross-stream dependency.  Fields = the parameters of gq_fc_step / gq_hand_pen_forward /
  * gq_hand_pen_backward of the same names.                                                                      */
+typedef struct gqHand gqHand; /* declared with gq_hand_create below */
 typedef struct gqFcStepDesc {
   const float* dist_sq; const int32_t* sign; const float* obj_dir; const float* closest;
   const float* contact_pts; const float* hand_normals; const float* cog;
@@ -117,6 +118,9 @@ typedef struct gqPenStepDesc {
   float* dis; int32_t* link; float* gvec;       /* link / gvec zero-initialised by the caller, see gq_hand_pen_forward */
   float* link_wrench; float* gRt; float w_pen; float* e_pen;
   uint64_t* span; uint64_t* span_acc;           /* optional in-kernel timing of the query, see gq_hand_pen_backward */
+  /* optional third role of the second launch: world sphere centres + self penetration (gq_self_pen_forward on the
+   * centres of link_T), so that gq_fk_forward can be called without spheres; hand == NULL: absent               */
+  const gqHand* hand; float w_spen; float* e_spen; float* g_sphere_centers; float* sphere_centers /* or NULL */;
 } gqPenStepDesc;
 int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream);
 

@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
     ap.add_argument("--hand", default="allegro")
     ap.add_argument("--fork", type=int, default=0, help="1: the two branches of the evaluation as parallel hipGraph branches (A/B)")
-    ap.add_argument("--graph_iters", type=int, default=4, help="MALA* iterations captured per hipGraph")
+    ap.add_argument("--graph_iters", type=int, default=8, help="MALA* iterations captured per hipGraph")
     ap.add_argument("--fused", type=int, default=1, help="1: force-closure and penetration branches share two launches (default)")
     ap.add_argument("--graph", type=int, default=1, help="replay the iteration from hipGraphs (1, default) or launch eagerly (0)")
     ap.add_argument("--no_cpu_baseline", action="store_true")

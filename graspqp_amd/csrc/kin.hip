@@ -203,6 +203,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   __shared__ float sWr[64 * 6];    // link wrenches of this row
   __shared__ int sLN[64];          // link -> node
   __shared__ int sCh[64];          // child lists
+  __shared__ float sG[128];        // the row's new gradient (accept step)
   const int row = blockIdx.x, lane = gq_lane();
   const gqHand& h = g.h;
   const float* hp = g.hand_pose + (size_t)row * g.D;
@@ -229,6 +230,28 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     Wj = gq_t_load(W + lane * 12);
   }
   if (lane < h.child_off[h.J]) sCh[lane] = h.child_idx[lane];  // J - (number of roots) entries
+  // inputs of the energy tail and of the accept step (independent of everything computed here)
+  float en_d2 = 0.0f, en_sg = 0.0f, en_jhi = 0.0f, en_jlo = 0.0f, en_th = 0.0f, en_efc = 0.0f, en_epen = 0.0f, en_espen = 0.0f;
+  gq3 en_on = gq_mk(0, 0, 0), en_nh = gq_mk(0, 0, 0);
+  if (g.en.total) {
+    if (lane < g.en.n) {
+      const size_t t = (size_t)row * g.en.n + lane;
+      en_d2 = g.en.dist_sq[t];
+      en_sg = (float)g.en.sign[t];
+      en_on = gq_mk(g.en.obj_dir[t * 3], g.en.obj_dir[t * 3 + 1], g.en.obj_dir[t * 3 + 2]);
+      en_nh = gq_mk(g.en.hand_normals[t * 3], g.en.hand_normals[t * 3 + 1], g.en.hand_normals[t * 3 + 2]);
+    }
+    if (lane < h.J) {
+      en_jhi = g.en.joints_upper[lane];
+      en_jlo = g.en.joints_lower[lane];
+      en_th = hp[9 + lane];
+    }
+    en_efc = g.en.e_fc[row];
+    en_epen = g.en.e_pen[row];
+    en_espen = g.en.e_spen[row];
+  }
+  GqAcceptPre ap{};
+  if (g.has_accept) ap = gq_accept_prefetch(g.ac, row, lane);
   __syncthreads();
   // ---- items: per-lane contribution to the global pose + (f, m) on the carrying node -----------------------------
   float acc[12];  // gt (3), gR (9) partial sums of this lane
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     float gth = (ntype == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
     if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + lane];
     if (g.en.total) {  // E_joints = sum relu(theta - hi) + relu(lo - theta)  (energy.py:47-54)
-      const float th = hp[9 + lane], hi = g.en.joints_upper[lane], lo = g.en.joints_lower[lane];
+      const float th = en_th, hi = en_jhi, lo = en_jlo;
       if (th > hi) {
         ej += th - hi;
         gth += g.en.w_joints;
@@ -336,10 +359,17 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
       }
     }
     go[9 + lane] = gth;
+    sG[9 + lane] = gth;
   }
+  float e_dis = 0.0f, e_joints = 0.0f, total = 0.0f;
   if (g.en.total) {
     float ed = 0.0f;  // E_dis = sum_i exp(1 + vC_i . nH_i) |d_i|  (energy.py:25-28)
-    for (int c = lane; c < g.en.n; c += GQ_WAVE) {
+    if (lane < g.en.n) {
+      const float root = sqrtf(en_d2 + 1e-8f);
+      const float dt = en_sg * (en_on.x * en_nh.x + en_on.y * en_nh.y + en_on.z * en_nh.z);
+      ed += expf(1.0f + dt) * root;
+    }
+    for (int c = lane + GQ_WAVE; c < g.en.n; c += GQ_WAVE) {
       const size_t t = (size_t)row * g.en.n + c;
       const float root = sqrtf(g.en.dist_sq[t] + 1e-8f);
       const float sg = (float)g.en.sign[t];
@@ -347,12 +377,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
                              g.en.obj_dir[t * 3 + 2] * g.en.hand_normals[t * 3 + 2]);
       ed += expf(1.0f + dt) * root;
     }
-    const float e_dis = gq_dpp_sum(ed), e_joints = gq_dpp_sum(ej);
+    e_dis = gq_dpp_sum(ed);
+    e_joints = gq_dpp_sum(ej);
+    total = g.en.w_dis * e_dis + g.en.w_fc * en_efc + g.en.w_pen * en_epen + g.en.w_spen * en_espen + g.en.w_joints * e_joints;
     if (lane == 0) {
       g.en.e_dis[row] = e_dis;
       g.en.e_joints[row] = e_joints;
-      g.en.total[row] = g.en.w_dis * e_dis + g.en.w_fc * g.en.e_fc[row] + g.en.w_pen * g.en.e_pen[row] +
-                        g.en.w_spen * g.en.e_spen[row] + g.en.w_joints * e_joints;
+      g.en.total[row] = total;
     }
   }
   // ---- global pose: fixed-tree sums over the lanes ---------------------------------------------------------------------
@@ -374,6 +405,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
           gR[i * 3 + j] += R[i * 3 + 0] * e[3 + 0 * 3 + j] + R[i * 3 + 1] * e[3 + 1 * 3 + j] + R[i * 3 + 2] * e[3 + 2 * 3 + j];
     }
     go[0] = gt.x; go[1] = gt.y; go[2] = gt.z;
+    sG[0] = gt.x; sG[1] = gt.y; sG[2] = gt.z;
     // Gram-Schmidt backward: columns of gR are the gradients of x, y, z
     const gq3 a = gq_mk(hp[3], hp[4], hp[5]), b = gq_mk(hp[6], hp[7], hp[8]);
     const float na = sqrtf(gq_dot(a, a));
@@ -391,10 +423,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     const gq3 ga = (1.0f / na) * (gx - gq_dot(gx, x) * x);
     go[3] = ga.x; go[4] = ga.y; go[5] = ga.z;
     go[6] = gb.x; go[7] = gb.y; go[8] = gb.z;
+    sG[3] = ga.x; sG[4] = ga.y; sG[5] = ga.z;
+    sG[6] = gb.x; sG[7] = gb.y; sG[8] = gb.z;
   }
-  if (g.has_accept) {  // Metropolis test on the total just written, state merge of this row
-    __threadfence_block();
-    gq_accept_body(g.ac, row, lane);
+  if (g.has_accept) {  // Metropolis test on the new total, state merge of this row -- from registers / LDS
+    __syncthreads();
+    const float term = lane == 0 ? e_dis : lane == 1 ? en_efc : lane == 2 ? en_epen : lane == 3 ? en_espen : e_joints;
+    gq_accept_finish(g.ac, ap, row, lane, total, sG, term);
   }
 }
 

@@ -138,3 +138,57 @@ __device__ __forceinline__ void gq_accept_body(const GqAcceptArgs& g, int row, i
   }
 }
 
+// The same step split for the FK backward kernel: everything that does not depend on the new energy is loaded (and
+// the temperature computed) at the top of the kernel; the finish takes the new energy and gradient from registers /
+// LDS instead of re-reading what the wavefront has just stored.
+struct GqAcceptPre {
+  float u, e_old, T;
+  bool reset;
+  float pose_new[2];
+  int64_t idx_new;
+};
+__device__ __forceinline__ GqAcceptPre gq_accept_prefetch(const GqAcceptArgs& g, int row, int lane) {
+  GqAcceptPre p;
+  const size_t draw0 = g.slot_ctr ? (size_t)((g.slot_ctr[1] - 1) % g.slots) * g.B : 0;
+  p.u = g.u_accept[draw0 + row];
+  p.e_old = g.energy[row];
+  p.reset = g.reset_mask && g.reset_mask[row];
+  p.pose_new[0] = lane < g.D ? g.pose_new[(size_t)row * g.D + lane] : 0.0f;
+  p.pose_new[1] = lane + GQ_WAVE < g.D ? g.pose_new[(size_t)row * g.D + lane + GQ_WAVE] : 0.0f;
+  p.idx_new = lane < g.n ? g.idx_new[(size_t)row * g.n + lane] : 0;
+  float T = g.T0 * powf(g.decay, (float)(g.step[row] / g.annealing_period));
+  if (g.z) {
+    const float proba = 0.5f * (1.0f + erff(g.z[row] * 0.70710678118654752f));
+    T = T * (1.0f + proba);
+  }
+  p.T = T;
+  return p;
+}
+// e_new: the row's new total (wave-uniform); sG: the row's new gradient (D floats, LDS); term: lane t < n_terms holds
+// the t-th energy term of the new state.
+__device__ __forceinline__ void gq_accept_finish(const GqAcceptArgs& g, const GqAcceptPre& p, int row, int lane,
+                                                 float e_new, const float* sG, float term) {
+  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[0] = g.slot_ctr[1];
+  bool acc = p.u < expf((p.e_old - e_new) / p.T);
+  if (p.reset) acc = true;
+  if (lane == 0) {
+    g.accept[row] = acc ? 1 : 0;
+    if (g.temperature) g.temperature[row] = p.T;
+    if (acc) g.energy[row] = e_new;
+  }
+  if (acc) {  // wave-uniform
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int d = lane + GQ_WAVE * c;
+      if (d < g.D) {
+        const size_t o = (size_t)row * g.D + d;
+        g.pose[o] = p.pose_new[c];
+        g.grad[o] = sG[d];
+      }
+    }
+    if (lane < g.n) g.idx[(size_t)row * g.n + lane] = p.idx_new;
+    for (int c = lane + GQ_WAVE; c < g.n; c += GQ_WAVE) g.idx[(size_t)row * g.n + c] = g.idx_new[(size_t)row * g.n + c];
+    if (lane < g.n_terms) g.terms[(size_t)lane * g.B + row] = term;
+  }
+}
+

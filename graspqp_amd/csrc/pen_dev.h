@@ -4,6 +4,7 @@
 // can live in one kernel and share one LDS allocation.
 #pragma once
 #include "tri.h"
+#include "wave.h"
 
 // ---- mesh-set handle: concatenated face records of n_mesh meshes on the device -----------------------------------
 struct gqMeshSet {
@@ -424,10 +425,11 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
         }
       }
       const int nq = (grp < n_lgroups) ? 24 : 12;
+      gq_wave_sums_f<24>(part);  // all 24 lane sums at once (pairwise folding, fixed order)
 #pragma unroll
       for (int q = 0; q < 24; ++q) {
         if (q < nq) {
-          const float tot = gq_dpp_sum(part[q]);
+          const float tot = part[q];
           if (lane == 0) {
             if (grp < n_lgroups) {
               const int l = l0 + q / 6;

@@ -122,16 +122,6 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
   }
 }
 
-__global__ void gq_fc_dldx_kernel(const float* __restrict__ g_e, const float* __restrict__ svd,
-                                  const float* __restrict__ Ftr, int B, int nz, float svd_gain, float values_gain,
-                                  float* __restrict__ dl_dx) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)B * nz) return;
-  const int row = (int)(t / nz);
-  const float gval = g_e[row] * values_gain * expf(-svd_gain * svd[row]);
-  dl_dx[t] = gval * Ftr[t];
-}
-
 struct GqFcBwdArgs {
   const float* F;
   const float* x;

@@ -15,7 +15,7 @@ from typing import Dict, List, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgraspqp_hip.so")
+LIB_PATH = os.environ.get("GRASPQP_HIP_LIB") or os.path.join(_HERE, "lib", "libgraspqp_hip.so")  # env: A/B builds
 HEADER_PATH = os.path.join(_HERE, "..", "include", "graspqp_hip.h")
 
 _SCALARS = {

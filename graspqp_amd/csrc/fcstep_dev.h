@@ -103,14 +103,29 @@ template <int RPL>
 __device__ __forceinline__ int gq_qp_stop_rows(const float* __restrict__ resid, const float* __restrict__ mu, int B,
                                                int max_iter, float eps, int lim, int lane) {
   float rs[RPL][16], ms[RPL][16];
+  if ((max_iter & 3) == 0) {  // rows are 16-byte aligned: four iterations per load
 #pragma unroll
-  for (int k = 0; k < RPL; ++k) {
-    const int r = lane + GQ_WAVE * k;
+    for (int k = 0; k < RPL; ++k) {
+      const int r = lane + GQ_WAVE * k;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const bool ok = r < B && it < max_iter;
-      rs[k][it] = ok ? resid[(size_t)r * max_iter + it] : 0.0f;
-      ms[k][it] = ok ? mu[(size_t)r * max_iter + it] : 0.0f;
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = r < B && q * 4 < max_iter;
+        const float4 a = ok ? *reinterpret_cast<const float4*>(resid + (size_t)r * max_iter + q * 4) : make_float4(0, 0, 0, 0);
+        const float4 b = ok ? *reinterpret_cast<const float4*>(mu + (size_t)r * max_iter + q * 4) : make_float4(0, 0, 0, 0);
+        rs[k][q * 4] = a.x; rs[k][q * 4 + 1] = a.y; rs[k][q * 4 + 2] = a.z; rs[k][q * 4 + 3] = a.w;
+        ms[k][q * 4] = b.x; ms[k][q * 4 + 1] = b.y; ms[k][q * 4 + 2] = b.z; ms[k][q * 4 + 3] = b.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const int r = lane + GQ_WAVE * k;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const bool ok = r < B && it < max_iter;
+        rs[k][it] = ok ? resid[(size_t)r * max_iter + it] : 0.0f;
+        ms[k][it] = ok ? mu[(size_t)r * max_iter + it] : 0.0f;
+      }
     }
   }
   float run[RPL];

@@ -354,11 +354,14 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
     }
     __syncthreads();
     // as many 256-point slices as fit into the LDS list (a slice holds <= 256 entries, so at least four always do);
-    // the remaining slices are taken up again by the next round
+    // the remaining slices are taken up again by the next round.  The (slice, wave) counts are read once, 16 B each.
+    int4 cnt4[GQ_PENB_K];
+#pragma unroll
+    for (int k = 0; k < GQ_PENB_K; ++k) cnt4[k] = *reinterpret_cast<const int4*>(s_cnt + k * 4);
     int kfit = 0, run = 0;
 #pragma unroll
     for (int k = 0; k < GQ_PENB_K; ++k) {
-      const int tot = s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
+      const int tot = cnt4[k].x + cnt4[k].y + cnt4[k].z + cnt4[k].w;
       if (kfit == k && run + tot <= GQ_PENB_LIST) {
         kfit = k + 1;
         run += tot;
@@ -368,9 +371,8 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
 #pragma unroll
     for (int k = 0; k < GQ_PENB_K; ++k) {
       if (k < kfit) {
-        int off = run;
-        for (int q = 0; q < wv; ++q) off += s_cnt[k * 4 + q];
-        run += s_cnt[k * 4] + s_cnt[k * 4 + 1] + s_cnt[k * 4 + 2] + s_cnt[k * 4 + 3];
+        const int off = run + (wv > 0 ? cnt4[k].x : 0) + (wv > 1 ? cnt4[k].y : 0) + (wv > 2 ? cnt4[k].z : 0);
+        run += cnt4[k].x + cnt4[k].y + cnt4[k].z + cnt4[k].w;
         e_acc += dpos[k];
         if (w[k] != 0.0f) {
           const int pt = base + k * 256 + tid;

@@ -182,12 +182,14 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
   } else {
     ks = g.kstar[0];
   }
-  // best iterate of this row among iterations 0..k* (qpth returns the per-row best, not the last)
+  // best iterate of this row among iterations 0..k* (qpth returns the per-row best, not the last): the row's
+  // residuals are fetched together (lane it holds iteration it), then scanned from registers
   int bi = 0;
   {
+    const float mine = (lane < g.max_iter && lane < 64) ? g.resid[(size_t)row * g.max_iter + lane] : 0.0f;
     float bst = 0.0f;
     for (int it = 0; it <= ks; ++it) {
-      const float rs = g.resid[(size_t)row * g.max_iter + it];
+      const float rs = it < 64 ? gq_readlane(mine, it) : g.resid[(size_t)row * g.max_iter + it];
       if (it == 0 || rs < bst) {
         bst = rs;
         bi = it;

@@ -343,6 +343,35 @@ class GraspStepper:
                 self.kernel_events.append(timer)
             self._iteration(st, timer=timer)
 
+    def step_reset(self, reset_mask, new_pose, new_idx, draws=None):
+        """One iteration of fit.py:399-458 in which the rows of ``reset_mask`` are re-initialised (fit.py:408-422): after
+        the proposal their pose / contact indices are replaced by ``new_pose`` / ``new_idx`` (what the reference's
+        initialize_convex_hull writes; producing them is the caller's business), MalaStar.reset_envs zeroes their step
+        counter, gradient EMA and old gradient and makes the new pose the "old" one, and the accept step accepts them
+        unconditionally.  Launched eagerly with the stand-alone propose / accept kernels (this happens every few hundred
+        iterations); the device-side draw-slot counter is advanced by hand so that graph replays stay in step."""
+        self.flush()
+        self.draw(draws)
+        st = _C.stream_ptr()
+        m = reset_mask.to(self.dev, torch.bool)
+        self._propose(st)
+        self.pose_new[m] = new_pose.to(self.dev, torch.float32)[m]
+        self.idx_new[m] = new_idx.to(self.dev)[m]
+        self.step_count[m] = 0  # optimizer.py:275-284
+        self.ema[m] = 0
+        self.hand_pose[m] = self.pose_new[m]
+        self.contact_idx[m] = self.idx_new[m]
+        self.grad[m] = 0
+        self._evaluate(self.pose_new, self.idx_new, st)
+        rm = m.to(torch.uint8).contiguous()
+        B, D, n, mc = self.B, self.D, self.n, self.mala
+        _C.call("gq_mala_accept", _C.f32(self.total_new), _C.f32(self._cur[2]), _C.f32(self.z), _C.u8(rm),
+                _C.i64(self.step_count), _C.f32(self.pose_new), _C.i64(self.idx_new), _C.f32(self.grad_new), B, D, n,
+                float(mc["starting_temperature"]), float(mc["temperature_decay"]), int(mc["annealing_period"]),
+                _C.f32(self.energy), _C.f32(self.hand_pose), _C.i64(self.contact_idx), _C.f32(self.grad),
+                _C.u8(self.accept), _C.f32(self.temperature), 5, _C.f32(self.terms_new), _C.f32(self.terms), st)
+        self._slot_ctr += 1
+
     def flush(self):
         """Run the iterations that ``step`` has queued for a multi-iteration graph but not yet replayed."""
         if self._graph_pending:

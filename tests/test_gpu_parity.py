@@ -562,3 +562,74 @@ def test_stepper_other_configs(gq, hand_name, n, k, n_obj, be):
         outs.append((s2.energy.clone(), s2.hand_pose.clone(), s2.contact_idx.clone()))
     assert torch.isfinite(outs[0][0]).all()
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+def test_stepper_reset_iteration_matches_class_surface(gq, golden_dir):
+    """fit.py:408-422 -- an iteration with re-initialised rows: GraspStepper.step_reset == the MalaStar / HandModel route
+    (try_step -> overwrite the masked rows -> reset_envs -> energy -> accept_step(reset_mask)), with graph-replayed
+    iterations before and after it."""
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.core.optimizer import MalaStar
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    g = _load(golden_dir, "mala_allegro_sphere_b8_n4.npz")
+    be, n_obj = int(g["batch_size_each"]), int(g["n_obj"])
+    B = be * n_obj
+    spec = get_hand_spec("allegro")
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    draws = lambda s: (f32(f"s{s}_u_switch"), torch.tensor(g[f"s{s}_new_idx"]).cuda(), f32(f"s{s}_u_accept"))
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[[1, B - 2]] = True
+    new_pose = f32("hand_pose0").roll(3, 0)  # "fresh initial poses": other rows' start poses
+    new_idx = torch.tensor(g["contact_idx0"]).cuda().roll(3, 0)
+    # --- stepper: graph iteration, reset iteration, graph iteration
+    st = _stepper_from_fixture(gq, g, 4)
+    st.reset(f32("hand_pose0"), torch.tensor(g["contact_idx0"]).cuda())
+    st.capture()
+    st.step(draws=draws(1))
+    st.step_reset(mask, new_pose, new_idx, draws=draws(2))
+    assert st.accept.cpu().bool()[mask].all(), "re-initialised rows are accepted unconditionally"
+    st.step(draws=draws(3))
+    torch.cuda.synchronize()
+    # --- class-surface route
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=g["obj0_surface_points"].shape[0])
+    om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                              surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    hm.set_parameters(f32("hand_pose0").requires_grad_(), torch.tensor(g["contact_idx0"]).cuda())
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+
+    def total():
+        losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=list(w), svd_gain=0.1)
+        return sum(w[k] * v for k, v in losses.items())
+
+    opt = MalaStar(hm, switch_possibility=0.4, device="cuda", batch_size=be)
+    energy = total()
+    energy.sum().backward()
+    opt.zero_grad()
+    energy = energy.detach().clone()
+    for s in (1, 2, 3):
+        d = draws(s)
+        opt.try_step(draws=d[:2])
+        eb = energy.view(-1, be)
+        z = ((eb - eb.mean(-1, keepdim=True)) / eb.std(-1, keepdim=True)).view(-1)
+        rm = None
+        if s == 2:
+            rm = mask.cuda()
+            hp = hm.hand_pose.detach().clone()
+            ix = hm.contact_point_indices.clone()
+            hp[rm] = new_pose[rm]
+            ix[rm] = new_idx[rm]
+            hm.set_parameters(hp.requires_grad_(), ix)
+            opt.reset_envs(rm)
+        opt.zero_grad()
+        new_energy = total()
+        new_energy.sum().backward()
+        with torch.no_grad():
+            opt.accept_step(energy, new_energy, rm, z, 1.0, u_accept=d[2])
+    np.testing.assert_allclose(st.energy.cpu().numpy(), energy.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(st.hand_pose.cpu().numpy(), hm.hand_pose.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(st.contact_idx, hm.contact_point_indices)

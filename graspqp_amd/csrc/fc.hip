@@ -92,12 +92,12 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_energy_kernel(GqFcArgs g) {
   for (int a = 0; a < 6; ++a) r[a] = gq_dpp_sum(r[a]);
 #pragma unroll
   for (int i = 0; i < 21; ++i) gr[i] = gq_dpp_sum_d(gr[i]);
-  double Lm[21];
-  const bool ok = gq_chol6(gr, Lm);
+  double Lm[21], inv[6];
+  const bool ok = gq_chol6(gr, Lm, inv);
   double lp = 1.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) lp *= Lm[i * (i + 1) / 2 + i];
-  const float svd = ok ? (float)pow(lp, 1.0 / 6.0) : 0.0f;  // (prod sigma)^(1/6) = det(F F')^(1/12)
+  const float svd = ok ? powf((float)lp, 1.0f / 6.0f) : 0.0f;  // (prod sigma)^(1/6) = det(F F')^(1/12)
   float val = 0.0f;
 #pragma unroll
   for (int a = 0; a < 6; ++a) val = fmaf(r[a], r[a], val);
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
   }
 #pragma unroll
   for (int i = 0; i < 21; ++i) gr[i] = gq_dpp_sum_d(gr[i]);
-  double Lm[21];
-  const bool ok = gq_chol6(gr, Lm);
+  double Lm[21], inv[6];
+  const bool ok = gq_chol6(gr, Lm, inv);
   const float ge = g.g_e[row], svd = g.svd[row], val = g.val[row];
   const float ex = expf(-g.svd_gain * svd);
   const float gval = ge * g.values_gain * ex;
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_grad_kernel(GqFcBwdArgs g) {
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
       for (int t = 0; t < a; ++t) w[a] -= Lm[a * (a + 1) / 2 + t] * w[t];
-      w[a] /= Lm[a * (a + 1) / 2 + a];
+      w[a] *= inv[a];
     }
 #pragma unroll
     for (int a = 5; a >= 0; --a) {
 #pragma unroll
       for (int t = a + 1; t < 6; ++t) w[a] -= Lm[t * (t + 1) / 2 + a] * w[t];
-      w[a] /= Lm[a * (a + 1) / 2 + a];
+      w[a] *= inv[a];
     }
     // gradient wrt the torque rows of column i (rows 3..5)
     gq3 gt;

@@ -2,6 +2,7 @@
 // fcstep.hip (the fused per-row kernels of the MALA* stepper).
 #pragma once
 #include "common.h"
+#include "wave.h"
 
 struct GqCone {
   gq3 f;    // cone edge (already divided by k)
@@ -36,8 +37,9 @@ __device__ __forceinline__ GqCone gq_cone_column(const float* cp, const float* c
   return o;
 }
 
-// 6x6 SPD Cholesky in double (every lane redundantly); returns false if not positive definite
-__device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21]) {
+// 6x6 SPD Cholesky in double (every lane redundantly); inv[i] = 1 / L_ii (Newton-refined rsqrt, no fp64 division or
+// square root on the dependent chain); returns false if not positive definite
+__device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21], double (&inv)[6]) {
   // packed lower triangle: idx(i,j) = i(i+1)/2 + j
   bool ok = true;
 #pragma unroll
@@ -52,15 +54,15 @@ __device__ __forceinline__ bool gq_chol6(double (&G)[21], double (&Lm)[21]) {
           ok = false;
           s = 1.0;
         }
-        Lm[i * (i + 1) / 2 + j] = sqrt(s);
+        inv[i] = gq_rsq_d(s);
+        Lm[i * (i + 1) / 2 + j] = s * inv[i];
       } else {
-        Lm[i * (i + 1) / 2 + j] = s / Lm[j * (j + 1) / 2 + j];
+        Lm[i * (i + 1) / 2 + j] = s * inv[j];
       }
     }
   }
   return ok;
 }
-
 
 // per-contact pieces of E_dis (energy.py:25-28) and of the contact normal fed to E_fc (object_model.py:246)
 struct GqContactTerm {

@@ -231,12 +231,12 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
 #pragma unroll
   for (int a = 0; a < 6; ++a) r[a] = gq_dpp_sum(r[a]);  // F x
   gq_wave_sums_d<21>(part);                             // F F'
-  double Lm[21];
-  const bool ok = gq_chol6(part, Lm);
+  double Lm[21], inv[6];
+  const bool ok = gq_chol6(part, Lm, inv);
   double lp = 1.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) lp *= Lm[i * (i + 1) / 2 + i];
-  const float svd = ok ? (float)pow(lp, 1.0 / 6.0) : 0.0f;  // (prod sigma)^(1/6) = det(F F')^(1/12)
+  const float svd = ok ? powf((float)lp, 1.0f / 6.0f) : 0.0f;  // (prod sigma)^(1/6) = det(F F')^(1/12)
   float val = 0.0f;
 #pragma unroll
   for (int a = 0; a < 6; ++a) val = fmaf(r[a], r[a], val);
@@ -280,9 +280,6 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
     for (int a = 0; a < 6; ++a) fd[a] = fmaf(S.a[c][a], live[c] ? dx[c] : 0.0f, fd[a]);
 #pragma unroll
   for (int a = 0; a < 6; ++a) fd[a] = gq_dpp_sum(fd[a]);  // F dx
-  double inv[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) inv[a] = gq_rcp_d(Lm[a * (a + 1) / 2 + a]);
   const float s6 = gsvd * svd / 6.0f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {

@@ -311,16 +311,20 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   float nf[6] = {0, 0, 0, 0, 0, 0};
   if (lane < h.J) {
     if (g.g_wrench) {
+#pragma unroll 4
       for (int l = 0; l < h.L; ++l) {
-        if (sLN[l] != lane) continue;
+        const float mine = (sLN[l] == lane) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) nf[k] += sWr[l * 6 + k];
+        for (int k = 0; k < 6; ++k) nf[k] = fmaf(mine, sWr[l * 6 + k], nf[k]);
       }
     }
-    for (int it = 0; it < n_items; ++it) {
-      if (sIn[it] != lane) continue;
+#pragma unroll 4
+    for (int it = 0; it < n_items; ++it) {  // branch-free: every lane reads the (broadcast) record, the owner adds it
+      // (a multiply, not a select: the compiler turns a select back into a branch around the LDS reads.  A non-finite
+      // record then reaches every node of the row -- harmless, a row with any NaN is zeroed by the proposal anyway)
+      const float mine = (sIn[it] == lane) ? 1.0f : 0.0f;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) nf[k] += sI[it * 6 + k];
+      for (int k = 0; k < 6; ++k) nf[k] = fmaf(mine, sI[it * 6 + k], nf[k]);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) sNF[lane * 6 + k] = nf[k];
@@ -389,7 +393,8 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   // ---- global pose: fixed-tree sums over the lanes ---------------------------------------------------------------------
   float tot[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) tot[i] = gq_dpp_sum(acc[i]);
+  for (int i = 0; i < 12; ++i) tot[i] = acc[i];
+  gq_wave_sums_f<12>(tot);  // all twelve lane sums at once (pairwise folding, fixed order)
   if (lane == 0) {
     gq3 gt = gq_mk(tot[0], tot[1], tot[2]);
     float gR[9];

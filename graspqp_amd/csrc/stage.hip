@@ -19,13 +19,16 @@
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream);
 
+#ifndef GQ_HEAD_ROWS
+#define GQ_HEAD_ROWS 4  // fc-head rows (wavefronts) per block of stage A
+#endif
 template <int NC>
 __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
   if (b < nfc) {  // four rows per block, one wavefront (= one SIMD) each: the fc role occupies B/4 CUs only
-    const int wv = (int)threadIdx.x / GQ_WAVE, row = b * 4 + wv;
-    if (row >= f.B) return;
+    const int wv = (int)threadIdx.x / GQ_WAVE, row = b * GQ_HEAD_ROWS + wv;
+    if (wv >= GQ_HEAD_ROWS || row >= f.B) return;
     gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6);
   } else {
     const int q = b - nfc;
@@ -109,7 +112,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
     sp.D = pen->pose_dim;
     n_sp = (f.B + 3) / 4;
   }
-  const int nfc = (f.B + 3) / 4;
+  const int nfc = (f.B + GQ_HEAD_ROWS - 1) / GQ_HEAD_ROWS;
   const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)4 * f.n * 6 * sizeof(float));
   const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
                                 n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);

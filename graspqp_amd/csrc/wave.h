@@ -3,20 +3,17 @@
 #pragma once
 #include "common.h"
 
-// 1/x and 1/sqrt(x) in fp64: hardware seed (v_rcp_f64 / v_rsq_f64) + two Newton steps (error e -> e^2 -> e^4, full
-// double precision from any seed better than 2^-14).  A full IEEE division costs ~12 dependent fp64 instructions;
-// the factorisation below runs wave-uniform on a single wave per SIMD, so that latency is paid in full every time.
+// 1/x and 1/sqrt(x) in fp64: hardware seed (v_rcp_f64 / v_rsq_f64, measured relative error 4.5e-8 / 5.1e-8 on gfx950,
+// tools/probe/rcp_probe.hip) + ONE Newton step -> 2e-15 / 4e-15, far below what the 6x6 systems need.  A full IEEE
+// division costs ~12 dependent fp64 instructions; the factorisation runs wave-uniform on a single wave per SIMD, so
+// every dependent instruction is paid at full latency.
 __device__ __forceinline__ double gq_rcp_d(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
 }
 __device__ __forceinline__ double gq_rsq_d(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
-  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(x);
+  return fma(fma(-0.5 * x * r, r, 0.5), r, r);
 }
 
 struct GqD2 {

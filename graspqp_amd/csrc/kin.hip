@@ -34,11 +34,12 @@ struct GqFkArgs {
 // a single wavefront, or -- with the object SDF attached -- wavefront 0 plus query wavefronts that wait at the one
 // block barrier further down).
 __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, int lane, float* sW, float* sT, float* sC,
-                                                  unsigned long long* sKey, float* sRad, float* sCP) {
+                                                  unsigned long long* sKey, float* sRad, float* sCP, float* sPose) {
   const gqHand& h = g.h;
   // The constant hand tables this lane needs (its joint node, its link, its first sphere, its sphere group) are loaded
   // BEFORE anything else: a single wavefront per row hides no latency, and the barriers / fences below would otherwise
   // turn every table into a dependent memory round trip of its own.
+  const int slot_now = (g.has_propose && g.pr.slot_ctr) ? g.pr.slot_ctr[0] : -1;  // requested first: loads depend on it
   int parent = -1, depth = -1, ntype = 0, lnode = -1;
   GqT pre = gq_t_identity(), loff = gq_t_identity();
   gq3 ax = gq_mk(0, 0, 0);
@@ -53,16 +54,22 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
     lnode = h.link_node[lane];
     loff = gq_t_load(h.link_offset + lane * 12);
   }
-  if (g.has_propose) {  // the proposal of this row, then its forward kinematics
-    gq_propose_body(g.pr, row, lane);
-    __threadfence_block();
-  }
   const float* hp = g.hand_pose + (size_t)row * g.D;
+  int64_t my_idx = 0;
+  const bool z_here = !sCP || (int)blockDim.x < 2 * GQ_WAVE;  // otherwise wavefront 1 computes the z-score while it waits
+  if (g.has_propose) {  // the proposal of this row, then its forward kinematics: pose and indices are handed over in
+    gq_propose_body(g.pr, row, lane, sPose, &my_idx, z_here, slot_now);  // LDS / registers, no wait for its own stores
+    gq_wave_sync();
+    hp = sPose;
+    if (g.n > GQ_WAVE) __threadfence_block();  // contacts beyond the first 64 re-read their indices from memory
+  } else if (lane < g.n) {
+    my_idx = g.idx[(size_t)row * g.n + lane];
+  }
   // contact candidates of the (just proposed) indices: in flight while the tree is walked
   int cl0 = 0;
   gq3 cp0 = gq_mk(0, 0, 0), cn0 = gq_mk(0, 0, 0);
   if (lane < g.n) {
-    const int ci = (int)g.idx[(size_t)row * g.n + lane];
+    const int ci = (int)my_idx;
     cl0 = h.cand_link[ci];
     cp0 = gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]);
     cn0 = gq_mk(h.cand_nrm[ci * 3], h.cand_nrm[ci * 3 + 1], h.cand_nrm[ci * 3 + 2]);
@@ -137,16 +144,17 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ unsigned long long sKey[64];   // per sphere group: (pen, a, b) of the most penetrating pair
   __shared__ float sRad[256];
   __shared__ float sCP[GQ_WAVE * 3];        // world contact points handed to the query wavefronts
+  __shared__ float sPose[128];              // the proposed pose (head of the row's kinematics)
   const int row = blockIdx.x, lane = gq_lane(), wv = (int)threadIdx.x / GQ_WAVE;
   const int nw = (int)blockDim.x / GQ_WAVE;
   if (!g.has_sdf) {
-    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, nullptr);
+    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, nullptr, sPose);
     return;
   }
   // Two code paths so that the prefetched boxes are not live across the kinematics: wavefront 0 does the kinematics,
   // the others fetch mesh offsets and cluster boxes of their first query meanwhile; everybody meets at ONE barrier.
   if (wv == 0) {
-    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, sCP);
+    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, sCP, sPose);
     __syncthreads();
     for (int c = 0; c < g.n; c += nw) {
       const GqSdfPre pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + c, lane);
@@ -155,6 +163,8 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   } else {
     GqSdfPre pre;
     if (wv < g.n) pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + wv, lane);
+    // the z-score of the old energies (only the accept step needs it) is computed by wavefront 1 while it waits
+    if (wv == 1 && g.has_propose) gq_zscore_row(g.pr, row, lane);
     __syncthreads();
     if (wv < g.n) gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + wv, gq_fk_contact_point(g, sCP, row, wv), lane, pre);
     for (int c = wv + nw; c < g.n; c += nw) {

@@ -28,14 +28,21 @@ struct GqProposeArgs {
 };
 
 // one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
-__device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane) {
+// s_pose (LDS, D floats) / my_idx: optional copies of the proposal for the caller's own use (pose element d in s_pose[d],
+// the index of contact `lane` in *my_idx), so that the FK code of the same wavefront need not wait for its own stores;
+// with_z = false leaves the z-score to a separate gq_zscore_row call (e.g. by another, idle wavefront).
+__device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane);
+__device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane, float* s_pose = nullptr,
+                                                int64_t* my_idx = nullptr, bool with_z = true, int slot_now = -1) {
   float g2[2];
   g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
   g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
-  const size_t draw0 = g.slot_ctr ? (size_t)(g.slot_ctr[0] % g.slots) * g.B * g.n : 0;
-  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[1] = g.slot_ctr[0] + 1;  // read by the accept of this iteration
+  // slot_now >= 0: the caller has already read slot_ctr[0] (early, so that the dependent loads below need not wait for it)
+  const int ctr = g.slot_ctr ? (slot_now >= 0 ? slot_now : g.slot_ctr[0]) : 0;
+  const size_t draw0 = g.slot_ctr ? (size_t)(ctr % g.slots) * g.B * g.n : 0;
+  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[1] = ctr + 1;  // read by the accept of this iteration
   const int64_t st = g.step[row];
-  const float s = g.step_size * powf(g.decay, (float)(st / g.stepsize_period));
+  const float s = g.step_size * powf(g.decay, (float)((int)st / g.stepsize_period));  // 32-bit division: st < 2^31
   float v[2] = {0.0f, 0.0f};
   bool bad = false;
 #pragma unroll
@@ -59,17 +66,27 @@ __device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row,
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int d = lane + GQ_WAVE * c;
-    if (d < g.D) g.pose_out[(size_t)row * g.D + d] = zero_row ? 0.0f : v[c];
+    if (d < g.D) {
+      const float pv = zero_row ? 0.0f : v[c];
+      g.pose_out[(size_t)row * g.D + d] = pv;
+      if (s_pose) s_pose[d] = pv;
+    }
   }
   for (int c = lane; c < g.n; c += GQ_WAVE) {
     const size_t o = (size_t)row * g.n + c;
-    g.idx_out[o] = (g.u_switch[draw0 + o] < g.switch_p) ? g.new_idx[draw0 + o] : g.idx[o];
+    const int64_t ix = (g.u_switch[draw0 + o] < g.switch_p) ? g.new_idx[draw0 + o] : g.idx[o];
+    g.idx_out[o] = ix;
+    if (my_idx && c == lane) *my_idx = ix;
   }
   if (lane == 0) {
     g.step[row] = st + 1;
     if (g.s_out) g.s_out[row] = s;
   }
-  if (g.energy) {  // z = (E - mean_obj) / std_obj (unbiased) over the rows of this row's object
+  if (with_z) gq_zscore_row(g, row, lane);
+}
+// z = (E - mean_obj) / std_obj (unbiased) over the rows of this row's object (fit.py:403-406)
+__device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane) {
+  if (g.energy) {
     const float* e = g.energy + (size_t)(row / g.batch_each) * g.batch_each;
     float acc = 0.0f;
     for (int i = lane; i < g.batch_each; i += GQ_WAVE) acc += e[i];
@@ -114,7 +131,7 @@ struct GqAcceptArgs {
 __device__ __forceinline__ void gq_accept_body(const GqAcceptArgs& g, int row, int lane) {
   const size_t draw0 = g.slot_ctr ? (size_t)((g.slot_ctr[1] - 1) % g.slots) * g.B : 0;
   if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[0] = g.slot_ctr[1];
-  float T = g.T0 * powf(g.decay, (float)(g.step[row] / g.annealing_period));
+  float T = g.T0 * powf(g.decay, (float)((int)g.step[row] / g.annealing_period));
   if (g.z) {
     const float proba = 0.5f * (1.0f + erff(g.z[row] * 0.70710678118654752f));
     T = T * (1.0f + proba);
@@ -156,7 +173,7 @@ __device__ __forceinline__ GqAcceptPre gq_accept_prefetch(const GqAcceptArgs& g,
   p.pose_new[0] = lane < g.D ? g.pose_new[(size_t)row * g.D + lane] : 0.0f;
   p.pose_new[1] = lane + GQ_WAVE < g.D ? g.pose_new[(size_t)row * g.D + lane + GQ_WAVE] : 0.0f;
   p.idx_new = lane < g.n ? g.idx_new[(size_t)row * g.n + lane] : 0;
-  float T = g.T0 * powf(g.decay, (float)(g.step[row] / g.annealing_period));
+  float T = g.T0 * powf(g.decay, (float)((int)g.step[row] / g.annealing_period));
   if (g.z) {
     const float proba = 0.5f * (1.0f + erff(g.z[row] * 0.70710678118654752f));
     T = T * (1.0f + proba);

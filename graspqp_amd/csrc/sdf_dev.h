@@ -119,27 +119,57 @@ __device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q
       }
       for (;;) {
         int pick[GQ_TOPK];
+        // which clusters can still beat the best distance?  (wave-uniform bit masks, one per register slot)
+        unsigned long long cm[KC];
+        int n_cand = 0;
 #pragma unroll
-        for (int j = 0; j < GQ_TOPK; ++j) {
-          float m = lb[0];
-          int mk = 0;
+        for (int k = 0; k < KC; ++k) {
+          cm[k] = __ballot(lb[k] <= ub && lb[k] < GQ_INF_F);
+          n_cand += __popcll(cm[k]);
+        }
+        if (n_cand == 0) break;
+        if (n_cand <= GQ_TOPK) {
+          // few left (the usual case after the first round): take them all, straight from the masks -- scalar bit
+          // operations instead of GQ_TOPK wave-wide minimum reductions
 #pragma unroll
-          for (int k = 1; k < KC; ++k) {
-            if (lb[k] < m) {
-              m = lb[k];
-              mk = k;
+          for (int j = 0; j < GQ_TOPK; ++j) {
+            int pk = -1;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+              if (pk < 0 && cm[k] != 0ull) {
+                const int src = __ffsll((long long)cm[k]) - 1;
+                pk = cb + k * GQ_WAVE + src;
+                cm[k] &= cm[k] - 1ull;
+              }
             }
+            pick[j] = pk;
           }
-          const float mw = gq_dpp_min(m);
-          pick[j] = -1;
-          if (mw <= ub) {  // wave-uniform; false when everything is visited (inf) or NaN
-            const unsigned long long who = __ballot(m == mw);
-            const int src = __ffsll((long long)who) - 1;
-            pick[j] = cb + gq_readlane_i(mk, src) * GQ_WAVE + src;
-            if (lane == src) {
 #pragma unroll
-              for (int k = 0; k < KC; ++k)
-                if (k == mk) lb[k] = GQ_INF_F;
+          for (int k = 0; k < KC; ++k)
+            if (lb[k] <= ub) lb[k] = GQ_INF_F;  // visited
+        } else {
+#pragma unroll
+          for (int j = 0; j < GQ_TOPK; ++j) {
+            float m = lb[0];
+            int mk = 0;
+#pragma unroll
+            for (int k = 1; k < KC; ++k) {
+              if (lb[k] < m) {
+                m = lb[k];
+                mk = k;
+              }
+            }
+            const float mw = gq_dpp_min(m);
+            pick[j] = -1;
+            if (mw <= ub && mw < GQ_INF_F) {  // wave-uniform; false when everything is visited (inf) or NaN
+              const unsigned long long who = __ballot(m == mw);
+              const int src = __ffsll((long long)who) - 1;
+              pick[j] = cb + gq_readlane_i(mk, src) * GQ_WAVE + src;
+              if (lane == src) {
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                  if (k == mk) lb[k] = GQ_INF_F;
+              }
             }
           }
         }

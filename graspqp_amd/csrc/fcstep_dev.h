@@ -171,6 +171,23 @@ template <int NC, int RPL>
 __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, float* sh) {
   const int lane = gq_lane();
   const int nz = g.nz;
+  // loads that depend on nothing computed here go first: the row's columns of F and the E_dis part of the contact
+  // gradient that the E_fc part is added to at the very end
+  GqLr<6, NC> S;
+  S.ridge = g.ridge;
+  bool live[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = lane + GQ_WAVE * c;
+    live[c] = i < nz;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) S.a[c][q] = live[c] ? g.F[((size_t)row * 6 + q) * nz + i] : 0.0f;
+  }
+  gq3 gc0 = gq_mk(0, 0, 0);
+  if (lane < g.n) {
+    const float* o = g.g_cpts + ((size_t)row * g.n + lane) * 3;
+    gc0 = gq_mk(o[0], o[1], o[2]);
+  }
   int ks;
   if (RPL > 0) {
     ks = gq_qp_stop_rows<(RPL > 0 ? RPL : 1)>(g.resid, g.mu_tab, g.B, g.max_iter, g.eps, g.not_improved_lim, lane);
@@ -197,9 +214,6 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
     }
   }
   const float* sn = g.snap + (((size_t)row * g.max_iter + bi) * 5) * nz;
-  GqLr<6, NC> S;
-  S.ridge = g.ridge;
-  bool live[NC];
   float x[NC], du[NC], dl[NC], lam[NC];
   double part[21];
 #pragma unroll
@@ -208,11 +222,8 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int i = lane + GQ_WAVE * c;
-    live[c] = i < nz;
     x[c] = 0.0f;
     du[c] = dl[c] = 1.0f;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) S.a[c][q] = live[c] ? g.F[((size_t)row * 6 + q) * nz + i] : 0.0f;
     if (live[c]) {
       x[c] = sn[i];
       const float zu = sn[nz + i], zl = sn[2 * nz + i], su = sn[3 * nz + i], sl = sn[4 * nz + i];
@@ -321,9 +332,15 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
       sz += sh[(c * g.k + e) * 3 + 2];
     }
     float* o = g.g_cpts + ((size_t)row * g.n + c) * 3;
-    o[0] += sx;
-    o[1] += sy;
-    o[2] += sz;
+    if (c < GQ_WAVE) {  // c == lane: the E_dis part was fetched at the top
+      o[0] = gc0.x + sx;
+      o[1] = gc0.y + sy;
+      o[2] = gc0.z + sz;
+    } else {
+      o[0] += sx;
+      o[1] += sy;
+      o[2] += sz;
+    }
   }
 }
 

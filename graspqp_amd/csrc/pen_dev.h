@@ -398,11 +398,15 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
     // the 12 global sums; lane j adds entries j, j+64, ... into registers, then the fixed DPP tree adds the lanes.
     //   wrench f_l -= G, m_l -= x_h x G ; gsum += G ; K += x_h (x) G      (G = r[0..2], x_h = r[3..5])
     const int n_lgroups = (g.L + 3) / 4;
-    for (int grp = wv; grp <= n_lgroups; grp += 4) {  // wave-uniform
+    // the 12 global sums ride in accumulators 12..23 of the last link group when that group has at most two links
+    // (Allegro: 14 links -> 4 groups, one per wavefront); otherwise they are a group of their own
+    const bool ride = g.L - 4 * (n_lgroups - 1) <= 2;
+    for (int grp = wv; grp < (ride ? n_lgroups : n_lgroups + 1); grp += 4) {  // wave-uniform
       float part[24];
 #pragma unroll
       for (int q = 0; q < 24; ++q) part[q] = 0.0f;
       const int l0 = grp * 4;
+      const bool ride_here = ride && grp == n_lgroups - 1;
       for (int i = lane; i < n; i += GQ_WAVE) {
         const float* r = s_rec + i * 6;
         const gq3 G = gq_mk(r[0], r[1], r[2]), x = gq_mk(r[3], r[4], r[5]);
@@ -418,6 +422,12 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
             part[q4 * 6 + 3] -= sel * mm.x;
             part[q4 * 6 + 4] -= sel * mm.y;
             part[q4 * 6 + 5] -= sel * mm.z;
+          }
+          if (ride_here) {
+            part[12] += G.x; part[13] += G.y; part[14] += G.z;
+            part[15] += x.x * G.x; part[16] += x.x * G.y; part[17] += x.x * G.z;
+            part[18] += x.y * G.x; part[19] += x.y * G.y; part[20] += x.y * G.z;
+            part[21] += x.z * G.x; part[22] += x.z * G.y; part[23] += x.z * G.z;
           }
         } else {
           part[0] += G.x; part[1] += G.y; part[2] += G.z;
@@ -437,6 +447,9 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
               const int l = l0 + q / 6;
               if (l < g.L) {
                 float* dst = g.wrench + ((size_t)row * g.L + l) * 6 + (q % 6);
+                *dst = (first ? 0.0f : *dst) + tot;
+              } else if (ride_here && q >= 12) {
+                float* dst = g.gRt + (size_t)row * 12 + (q - 12);
                 *dst = (first ? 0.0f : *dst) + tot;
               }
             } else {

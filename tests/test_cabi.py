@@ -80,3 +80,37 @@ def test_metric_factory_surface():
         GF.create(GF.MetricType.TDG)
     s = SQPLsqSolver.from_mat(torch.zeros(2, 1, 6, 48), torch.zeros(2, 1, 6))
     assert s._batch_size == 2 and s._num_wrenches == 48
+
+
+def test_descriptor_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the descriptor structs (graspqp_amd/_C.py) must have the size and field offsets that a C
+    compiler gives the structs of include/graspqp_hip.h -- a silent mismatch would hand garbage pointers to kernels."""
+    import ctypes
+    import shutil
+    import subprocess
+
+    from graspqp_amd import _C
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"gqHandDesc": _C.HandDesc, "gqRowEnergyDesc": _C.RowEnergyDesc, "gqFcStepDesc": _C.FcStepDesc,
+             "gqPenStepDesc": _C.PenStepDesc, "gqProposeDesc": _C.ProposeDesc, "gqAcceptDesc": _C.AcceptDesc,
+             "gqSdfDesc": _C.SdfDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "graspqp_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
+    subprocess.check_call(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().strip().splitlines()
+    for line in out:
+        name, *nums = line.split()
+        cls = pairs[name]
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in nums] == want, f"{name}: C {nums} vs ctypes {want}"

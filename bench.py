@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--n_contact", type=int, default=12)
+    ap.add_argument("--n_cone_vecs", type=int, default=4, help="friction-cone edges per contact (BASELINE configs[4] uses 8)")
     ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
     ap.add_argument("--hand", default="allegro")
     ap.add_argument("--fork", type=int, default=0, help="1: the two branches of the evaluation as parallel hipGraph branches (A/B)")
@@ -118,7 +119,8 @@ def main():
     sps = [meshes.surface_points(f, 2500, oversample=4, seed=42) for f in fvs]
     B = len(my_objs) * args.batch_size
     hand = ops.HandHandle(spec)
-    st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact, seed=1 + rank)
+    st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact,
+                      fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank)
     hps, idxs = zip(*[make_initial_state(spec, f, args.batch_size, args.n_contact, 1000 + o) for f, o in zip(fvs, my_objs)])
     st.reset(torch.cat(hps).cuda(), torch.cat(idxs).cuda())
 
@@ -195,13 +197,17 @@ def main():
                     # (70 flop per point-triangle test) against the 157.3 TFLOP/s vector peak.  The kernel EXECUTES far
                     # fewer tests (voxel candidate lists), so this is an equivalent rate, not a utilisation.
                     "fp32_alu_frac_bruteforce_equivalent": pair_tests * 70.0 / (k_ms * 1e-3) / 157.3e12}
+        # BASELINE.json's metric on its configuration; other hands / contact counts (parity-size cases) are labelled as such
+        hand_label = {"allegro": "Allegro", "shadow_hand": "Shadow Hand", "robotiq3": "Robotiq-3F"}.get(args.hand, args.hand)
+        metric_name = f"grasp energy+grad evals/sec ({hand_label}, n_contact={args.n_contact})"
         res = {
-            "metric": "grasp energy+grad evals/sec (Allegro, n_contact=12)", "value": total_evals / dt, "unit": "evals/s",
+            "metric": metric_name, "value": total_evals / dt, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": "kinematics / SDF / energies f32; force-closure QP (PDIPM + KKT backward) f64, as in the reference", "data": "synthetic",
             "config": {"workload": f"{args.hand}, {args.n_objects} YCB-style superquadric mesh(es) per GPU "
                                    f"({fvs[0].shape[0]} faces), batch_size={args.batch_size} each, n_contact={args.n_contact}, "
-                                   f"2500 surface points, 4-edge friction cones (BASELINE configs[1])",
+                                   f"2500 surface points, {args.n_cone_vecs}-edge friction cones"
+                                   + (" (BASELINE configs[1])" if (args.hand, args.n_objects, args.batch_size, args.n_contact, args.n_cone_vecs) == ("allegro", 1, 256, 12, 4) else ""),
                        "rows_per_gpu": B, "hip_graph": bool(args.graph), "iterations_per_graph": args.graph_iters if args.graph else 0, "branches": ("one grid" if args.fused else "graph branches" if args.fork else "serial") if args.graph else "eager"},
             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "mean_energy": float(st.energy.mean()), "accept_rate_last": float(st.accept.float().mean()),
             "roofline": roof,

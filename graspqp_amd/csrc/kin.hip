@@ -260,6 +260,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     en_epen = g.en.e_pen[row];
     en_espen = g.en.e_spen[row];
   }
+  // what lane 0 needs at the very end (global-pose part): fetched now, one value per lane, handed over by readlane
+  float rt_l = 0.0f, pose_l = 0.0f;
+  if (g.g_Rt && lane < 12) rt_l = g.g_Rt[(size_t)row * 12 + lane];
+  if (lane < 9) pose_l = hp[lane];
   GqAcceptPre ap{};
   if (g.has_accept) ap = gq_accept_prefetch(g.ac, row, lane);
   __syncthreads();
@@ -411,7 +415,9 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
 #pragma unroll
     for (int i = 0; i < 9; ++i) gR[i] = tot[3 + i] + (g.g_R ? g.g_R[(size_t)row * 9 + i] : 0.0f);
     if (g.g_Rt) {  // grad_t = -R gsum ; grad_R = R K
-      const float* e = g.g_Rt + (size_t)row * 12;
+      float e[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) e[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rt_l), i));
       gt = gt - gq_mv(R, gq_mk(e[0], e[1], e[2]));
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -422,7 +428,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
     go[0] = gt.x; go[1] = gt.y; go[2] = gt.z;
     sG[0] = gt.x; sG[1] = gt.y; sG[2] = gt.z;
     // Gram-Schmidt backward: columns of gR are the gradients of x, y, z
-    const gq3 a = gq_mk(hp[3], hp[4], hp[5]), b = gq_mk(hp[6], hp[7], hp[8]);
+    float pz[9];
+#pragma unroll
+    for (int i = 3; i < 9; ++i) pz[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pose_l), i));
+    const gq3 a = gq_mk(pz[3], pz[4], pz[5]), b = gq_mk(pz[6], pz[7], pz[8]);
     const float na = sqrtf(gq_dot(a, a));
     const gq3 x = (1.0f / na) * a;
     const gq3 yp = b - gq_dot(x, b) * x;

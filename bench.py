@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--graph_iters", type=int, default=8, help="MALA* iterations captured per hipGraph")
     ap.add_argument("--fused", type=int, default=1, help="1: force-closure and penetration branches share two launches (default)")
     ap.add_argument("--graph", type=int, default=1, help="replay the iteration from hipGraphs (1, default) or launch eagerly (0)")
+    ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL, default) | gloo: rehearsal of the multi-process path "
+                    "on fewer GPUs than ranks (ranks share devices round-robin; collectives go through host memory)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_rows", type=int, default=8)
     args = ap.parse_args()
@@ -101,8 +103,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
 
@@ -155,12 +161,14 @@ def main():
     evs, span_iso_ms, _ = st.kernel_times_ms()
     st._graph = g
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda")
+        cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # optional gather of the final energies (the only collective of a run; 1 KB per rank)
-        out = [torch.empty_like(st.energy) for _ in range(world)]
-        dist.all_gather(out, st.energy)
+        e_fin = st.energy.to(cdev)
+        out = [torch.empty_like(e_fin) for _ in range(world)]
+        dist.all_gather(out, e_fin)
     assert torch.isfinite(st.energy).all(), "non-finite energies"
 
     if rank == 0:

@@ -496,6 +496,11 @@ def test_config2_properties_and_determinism(gq):
     for k, i in (("E_dis", 0), ("E_pen", 2), ("E_spen", 3), ("E_joints", 4)):
         np.testing.assert_allclose(t2[k][rows].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
     np.testing.assert_allclose(t2["E_fc"][rows].cpu().numpy(), lo["E_fc"].detach().numpy(), rtol=0.3)
+    # E_fc at the FULL batch: the oracle's force-closure metric (fp64) on the 256 x 12 contact points / object normals
+    # the GPU evaluated -- identical batch composition, so qpth's batch-global stop rule sees the same rows
+    eo, _ = ospan.e_fc(st2.cpts.cpu().double(), st2.obj_normal.cpu().double(), st2.cog.cpu().double(), k=4, box_form=True)
+    rel = _rel(t2["E_fc"].cpu().numpy(), eo.numpy())
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -548,6 +553,10 @@ def test_stepper_other_configs(gq, hand_name, n, k, n_obj, be):
         for kk in ("E_dis", "E_pen", "E_spen", "E_joints"):
             np.testing.assert_allclose(terms[kk][r].item(), lo[kk].item(), rtol=3e-4, atol=3e-6, err_msg=f"{kk} row {r}")
         np.testing.assert_allclose(terms["E_fc"][r].item(), lo["E_fc"].item(), rtol=0.3)
+    # E_fc tightly: the oracle's metric on the whole batch of contact points the GPU evaluated (same stop-rule input)
+    eo, _ = ospan.e_fc(st.cpts.cpu().double(), st.obj_normal.cpu().double(), st.cog.cpu().double(), k=k, box_form=True)
+    rel = _rel(terms["E_fc"].cpu().numpy(), eo.numpy())
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
     # (3) iterations run (graph replay == eager), stay finite and are reproducible
     outs = []
     for rep in range(2):

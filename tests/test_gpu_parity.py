@@ -496,6 +496,14 @@ def test_config2_properties_and_determinism(gq):
     for k, i in (("E_dis", 0), ("E_pen", 2), ("E_spen", 3), ("E_joints", 4)):
         np.testing.assert_allclose(t2[k][rows].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
     np.testing.assert_allclose(t2["E_fc"][rows].cpu().numpy(), lo["E_fc"].detach().numpy(), rtol=0.3)
+    # gradient of everything but E_fc (whose stop rule depends on the batch) for the sampled rows, norm-wise
+    w0 = {"E_dis": 100.0, "E_fc": 0.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    st3 = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n, weights=w0)
+    _, _, g3 = st3.evaluate(pose, st.contact_idx)
+    sum(w0[k] * lo[k] for k in w0 if w0[k] != 0.0).sum().backward()
+    go = hpo.grad.numpy()
+    gerr = np.linalg.norm(g3[rows].cpu().numpy() - go) / np.linalg.norm(go)
+    assert gerr < 1e-3, gerr
     # E_fc at the FULL batch: the oracle's force-closure metric (fp64) on the 256 x 12 contact points / object normals
     # the GPU evaluated -- identical batch composition, so qpth's batch-global stop rule sees the same rows
     eo, _ = ospan.e_fc(st2.cpts.cpu().double(), st2.obj_normal.cpu().double(), st2.cog.cpu().double(), k=4, box_form=True)

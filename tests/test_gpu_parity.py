@@ -509,6 +509,15 @@ def test_config2_properties_and_determinism(gq):
     eo, _ = ospan.e_fc(st2.cpts.cpu().double(), st2.obj_normal.cpu().double(), st2.cog.cpu().double(), k=4, box_form=True)
     rel = _rel(t2["E_fc"].cpu().numpy(), eo.numpy())
     assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    # ... and its gradient w.r.t. the contact points (KKT-implicit QP backward + direct + singular-value parts), full batch
+    st4 = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n,
+                                  weights={"E_dis": 0.0, "E_fc": 1.0, "E_pen": 0.0, "E_spen": 0.0, "E_joints": 0.0})
+    st4.evaluate(pose, st.contact_idx)
+    po = st4.cpts.cpu().double().requires_grad_()
+    e4, _ = ospan.e_fc(po, st4.obj_normal.cpu().double(), st4.cog.cpu().double(), k=4, box_form=True)
+    e4.sum().backward()
+    gfc = np.linalg.norm(st4.g_cpts.cpu().numpy() - po.grad.numpy()) / np.linalg.norm(po.grad.numpy())
+    assert gfc < 2e-2, gfc
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -131,78 +131,100 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_qp_stop_wave_kernel(const float* _
   }
 }
 
-// same rule for up to 4096 rows: 1024 threads, RPT rows per thread, both tables in registers after ONE round of loads,
-// then per iteration a DPP reduction per wavefront and a 16-entry LDS exchange.
-template <int RPT>
-__global__ __launch_bounds__(1024) void gq_qp_stop_block_kernel(const float* __restrict__ resid,
+// same rule for any number of rows, one block of 1024 threads.  The per-row running best does not depend on where the
+// batch stops, so every thread replays its rows (one per 1024-row tile) over ALL iterations and keeps, per iteration,
+// "some row of mine improved" / max of the running bests / min of mu; ONE block reduction at the end yields the three
+// per-iteration aggregates and thread 0 applies the sequential rule to them.  The (rows, max_iter) tables are read as
+// contiguous streams and transposed through LDS -- a thread reading "its" row directly costs one cache line per lane
+// and load instruction, which made the previous variant L1-bound (33 us at 2048 rows).
+__global__ __launch_bounds__(1024) void gq_qp_stop_tiled_kernel(const float* __restrict__ resid,
                                                                 const float* __restrict__ mu, int B, int max_iter,
                                                                 float eps, int not_improved_lim, int* __restrict__ kstar,
                                                                 int* __restrict__ n_iter_out) {
-  __shared__ float s_mx[2][16], s_mn[2][16];
-  __shared__ int s_any[2][16];
+  __shared__ float s_tab[1024 * GQ_STOP_MAXIT];
+  __shared__ float s_mx[16][GQ_STOP_MAXIT], s_mn[16][GQ_STOP_MAXIT];
+  __shared__ unsigned s_any[16];
   const int tid = threadIdx.x, lane = gq_lane(), wv = tid / GQ_WAVE;
-  float rs[RPT][GQ_STOP_MAXIT], mt[GQ_STOP_MAXIT];  // mt[it] = min of mu over this thread's rows (only the min is used)
-#pragma unroll
-  for (int it = 0; it < GQ_STOP_MAXIT; ++it) mt[it] = GQ_INF;
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    const int r = tid + 1024 * k;
-#pragma unroll
-    for (int it = 0; it < GQ_STOP_MAXIT; ++it) {
-      const bool ok = r < B && it < max_iter;
-      rs[k][it] = ok ? resid[(size_t)r * max_iter + it] : 0.0f;
-      if (ok) mt[it] = gq_nanmin(mt[it], mu[(size_t)r * max_iter + it]);
-    }
-  }
-  float run[RPT];
-  int not_improved = 0, stop_at = max_iter - 1;
-  bool done = false;
+  float amx[GQ_STOP_MAXIT], amn[GQ_STOP_MAXIT];
+  unsigned aany = 0u;
 #pragma unroll
   for (int it = 0; it < GQ_STOP_MAXIT; ++it) {
-    if (it < max_iter && !done) {  // block-uniform
-      float mx = -GQ_INF, mn = GQ_INF;
-      bool any = false;
+    amx[it] = -GQ_INF;
+    amn[it] = GQ_INF;
+  }
+  for (int r0 = 0; r0 < B; r0 += 1024) {
+    const int nr = (B - r0 < 1024) ? B - r0 : 1024;
+    const int tot = nr * max_iter;
+    const bool mine = tid < nr;
+    float rs[GQ_STOP_MAXIT];
+    // both tiles are requested before anything is stored (a copy loop would wait for every load in turn)
+    float va[GQ_STOP_MAXIT], vb[GQ_STOP_MAXIT];
+    const float* src_a = resid + (size_t)r0 * max_iter;
+    const float* src_b = mu + (size_t)r0 * max_iter;
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        if (tid + 1024 * k < B) {
-          float bst = rs[k][it];
-          if (it > 0) {
-            bst = run[k];
-            if (rs[k][it] < bst) {
-              bst = rs[k][it];
-              any = true;
-            }
+    for (int j = 0; j < GQ_STOP_MAXIT; ++j) {
+      const int i = tid + 1024 * j;
+      va[j] = i < tot ? src_a[i] : 0.0f;
+      vb[j] = i < tot ? src_b[i] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < GQ_STOP_MAXIT; ++j)
+      if (tid + 1024 * j < tot) s_tab[tid + 1024 * j] = va[j];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < GQ_STOP_MAXIT; ++it) rs[it] = (mine && it < max_iter) ? s_tab[tid * max_iter + it] : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GQ_STOP_MAXIT; ++j)
+      if (tid + 1024 * j < tot) s_tab[tid + 1024 * j] = vb[j];
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int it = 0; it < GQ_STOP_MAXIT; ++it)
+        if (it < max_iter) amn[it] = gq_nanmin(amn[it], s_tab[tid * max_iter + it]);
+      float bst = rs[0];
+      amx[0] = gq_nanmax(amx[0], bst);
+#pragma unroll
+      for (int it = 1; it < GQ_STOP_MAXIT; ++it) {
+        if (it < max_iter) {
+          if (rs[it] < bst) {
+            bst = rs[it];
+            aany |= 1u << it;
           }
-          run[k] = bst;
-          mx = gq_nanmax(mx, bst);
+          amx[it] = gq_nanmax(amx[it], bst);
         }
       }
-      mn = mt[it];
-      const bool any_w = __ballot(any) != 0ull;
-      const float mxw = -gq_dpp_nanmin(-mx), mnw = gq_dpp_nanmin(mn);
-      const int par = it & 1;  // double-buffered exchange: one barrier per iteration
-      if (lane == 0) {
-        s_mx[par][wv] = mxw;
-        s_mn[par][wv] = mnw;
-        s_any[par][wv] = any_w ? 1 : 0;
-      }
-      __syncthreads();
-      float bmx = -GQ_INF, bmn = GQ_INF;
-      int bany = 0;
+    }
+    __syncthreads();  // the next tile overwrites s_tab
+  }
 #pragma unroll
-      for (int w = 0; w < 16; ++w) {
-        bmx = gq_nanmax(bmx, s_mx[par][w]);
-        bmn = gq_nanmin(bmn, s_mn[par][w]);
-        bany |= s_any[par][w];
-      }
-      not_improved = (it == 0) ? 0 : (bany ? 0 : not_improved + 1);
-      if ((not_improved == not_improved_lim) || (bmx < eps) || (bmn > 1e32f)) {
-        stop_at = it;
-        done = true;
-      }
+  for (int o = 32; o > 0; o >>= 1) aany |= (unsigned)__shfl_xor((int)aany, o, GQ_WAVE);
+#pragma unroll
+  for (int it = 0; it < GQ_STOP_MAXIT; ++it) {
+    const float mxw = -gq_dpp_nanmin(-amx[it]), mnw = gq_dpp_nanmin(amn[it]);
+    if (lane == 0) {
+      s_mx[wv][it] = mxw;
+      s_mn[wv][it] = mnw;
     }
   }
+  if (lane == 0) s_any[wv] = aany;
+  __syncthreads();
   if (tid == 0) {
+    unsigned any = 0u;
+    for (int w = 0; w < 16; ++w) any |= s_any[w];
+    int not_improved = 0, stop_at = max_iter - 1;
+    for (int it = 0; it < max_iter; ++it) {
+      float bmx = -GQ_INF, bmn = GQ_INF;
+      for (int w = 0; w < 16; ++w) {
+        bmx = gq_nanmax(bmx, s_mx[w][it]);
+        bmn = gq_nanmin(bmn, s_mn[w][it]);
+      }
+      not_improved = (it == 0) ? 0 : (((any >> it) & 1u) ? 0 : not_improved + 1);
+      if ((not_improved == not_improved_lim) || (bmx < eps) || (bmn > 1e32f)) {
+        stop_at = it;
+        break;
+      }
+    }
     kstar[0] = stop_at;
     kstar[1] = stop_at + 1;
     if (n_iter_out) *n_iter_out = stop_at + 1;
@@ -269,11 +291,8 @@ static void gq_qp_stop_dispatch(const float* resid, const float* mu, int B, int 
   if (B <= GQ_STOP_MAXB && max_iter <= GQ_STOP_MAXIT)
     hipLaunchKernelGGL(gq_qp_stop_wave_kernel, dim3(1), dim3(GQ_WAVE), 0, st, resid, mu, B, max_iter, eps, lim, runmin,
                        kstar, n_iter);
-  else if (B <= 2048 && max_iter <= GQ_STOP_MAXIT)
-    hipLaunchKernelGGL((gq_qp_stop_block_kernel<2>), dim3(1), dim3(1024), 0, st, resid, mu, B, max_iter, eps, lim, kstar,
-                       n_iter);
-  else if (B <= 4096 && max_iter <= GQ_STOP_MAXIT)
-    hipLaunchKernelGGL((gq_qp_stop_block_kernel<4>), dim3(1), dim3(1024), 0, st, resid, mu, B, max_iter, eps, lim, kstar,
+  else if (max_iter <= GQ_STOP_MAXIT)
+    hipLaunchKernelGGL(gq_qp_stop_tiled_kernel, dim3(1), dim3(1024), 0, st, resid, mu, B, max_iter, eps, lim, kstar,
                        n_iter);
   else
     hipLaunchKernelGGL(gq_qp_stop_kernel, dim3(1), dim3(256), 0, st, resid, mu, B, max_iter, eps, lim, runmin, kstar,

@@ -23,7 +23,7 @@ __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t*
 
 #include "sdf_dev.h"
 
-__global__ __launch_bounds__(256) void gq_sdf_wave_kernel(GqWaveArgs g) {
+__global__ __launch_bounds__(256, 4) void gq_sdf_wave_kernel(GqWaveArgs g) {  // <= 128 VGPRs: 4 wavefronts per SIMD
   const int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
   if (q >= g.N) return;
   const int lane = gq_lane();

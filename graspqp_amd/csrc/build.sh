@@ -7,6 +7,11 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
 OBJS=()
+PIDS=()
+# a changed flag set invalidates every object (hash of the flags kept beside them)
+SIG="$(echo "$FLAGS ${GQ_EXTRA_FLAGS:-}" | md5sum | cut -d' ' -f1)"
+[ "$(cat "$OUT/.flags" 2>/dev/null || true)" = "$SIG" ] || rm -f "$OUT"/*.o
+echo "$SIG" > "$OUT/.flags"
 deps() {  # headers each translation unit includes
   case "$1" in
     qp_lr|fcstep) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h" ;;
@@ -25,10 +30,12 @@ for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep stage lo
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done
   if [ $stale = 1 ]; then
     echo "[build] hipcc $f.hip"
+    rm -f "$OUT/$f.o"  # a failed compile must not leave a stale object for the link
     "$HIPCC" $FLAGS ${GQ_EXTRA_FLAGS:-} -c "$HERE/$f.hip" -o "$OUT/$f.o" &
+    PIDS+=($!)
   fi
   OBJS+=("$OUT/$f.o")
 done
-wait
+for p in "${PIDS[@]:-}"; do [ -z "$p" ] || wait "$p" || { echo "[build] a compile failed" >&2; exit 1; }; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$OUT/libgraspqp_hip.so"
 echo "[build] $OUT/libgraspqp_hip.so"

@@ -49,8 +49,11 @@ struct GqPenArgs {
   int32_t* link;  // (B, P)
   float* gvec;    // (B, P, 3)
   uint64_t* span;  // optional [min start, max end] of the launch in 100 MHz s_memrealtime ticks
-  unsigned long long* dbg;  // optional counters: [0] needing (point,link) pairs, [1] (wave,link) evaluations,
-                            // [2] (wave,sub-cluster) evaluations, [3] waves
+  unsigned long long* dbg;  // optional counters (8 words, gq_debug_set_pen_counters): [0] needing (point,link) pairs,
+                            // [1] (wave,link) evaluations, [2] (wave,sub-cluster) evaluations, [3] waves (AABB / queue
+                            // kernels); gq_pen_grid_body: [4] entries = (point,link) pairs that reach a non-empty
+                            // voxel, [5] executed point-triangle rankings, [6] entries ranked inline (LDS capacity
+                            // overflow), [7] blocks
 };
 
 // launch time span in 100 MHz s_memrealtime ticks, sharded 64 ways so the atomics of 1e3 blocks do not pile up on one
@@ -130,7 +133,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     s_sph[l * 4 + 2] = T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11];
     s_sph[l * 4 + 3] = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
   }
-  if (tid < 2) s_cnt[tid] = 0;
+  if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
   s_pkey[tid] = 0ull;
   const bool ok = pt < g.P;
   const int obj = row / g.batch_each;
@@ -162,6 +165,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
     const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
     if (len == 0u) continue;
+    if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
     const int e = atomicAdd(&s_cnt[0], 1);
     int ib = GQ_PG_ICAP;
     if (e < GQ_PG_ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
@@ -175,6 +179,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
       s_ekey[e] = ~0ull;
       for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
     } else {  // no room: rank the candidates here
+      if (g.dbg) atomicAdd(&s_cnt[2], 1);
       if (e < GQ_PG_ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
       // the part of the item list this entry reserved but does not use must not be read as items
       for (int i = ib; i < GQ_PG_ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
@@ -204,6 +209,12 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     }
   }
   __syncthreads();
+  if (g.dbg && tid == 0) {
+    atomicAdd(&g.dbg[4], (unsigned long long)s_cnt[0]);
+    atomicAdd(&g.dbg[5], (unsigned long long)s_cnt[3]);
+    atomicAdd(&g.dbg[6], (unsigned long long)s_cnt[2]);
+    atomicAdd(&g.dbg[7], 1ull);
+  }
   const int n_ent = min(s_cnt[0], GQ_PG_ECAP), n_item = min(s_cnt[1], GQ_PG_ICAP);
   // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
   for (int i = tid; i < n_item; i += 256) {

@@ -451,6 +451,15 @@ int gq_boxqp_forward(const float* Q, const float* p, const float* lower, const f
                               (hipStream_t)stream, 1);
 }
 
+// qpth's batch-global stop rule on a (B, max_iter) residual / mu table (what the forward entry points run after
+// their iterations); exposed so that the rule itself can be tested on arbitrary tables.
+int gq_boxqp_stop_rule(const float* resid, const float* mu, int64_t batch, int max_iter, float eps,
+                       int not_improved_lim, float* runmin_scratch, int32_t* kstar, int32_t* n_iter, void* stream) {
+  GQ_REQUIRE(resid && mu && runmin_scratch && kstar, "boxqp_stop_rule: null pointer");
+  GQ_REQUIRE(batch > 0 && batch < (1ll << 31) && max_iter >= 1 && max_iter <= 64, "boxqp_stop_rule: bad sizes");
+  return gq_qp_stop_launch_(resid, mu, (int)batch, max_iter, eps, not_improved_lim, runmin_scratch, kstar, n_iter, stream);
+}
+
 int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, const float* grad_x, int64_t batch,
                           int m, int nz, float ridge, float* dx, float* dlam, void* stream) {
   GQ_REQUIRE(A && lam && slack && grad_x && dx && dlam, "lsq_boxqp_backward: null pointer");

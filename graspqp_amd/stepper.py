@@ -372,6 +372,14 @@ class GraspStepper:
                 _C.u8(self.accept), _C.f32(self.temperature), 5, _C.f32(self.terms_new), _C.f32(self.terms), st)
         self._slot_ctr += 1
 
+    def realign_draws(self):
+        """Run queued iterations, then restart the 64-slot buffer of random draws at slot 0 (the next ``step`` refills
+        it): afterwards a multi-iteration graph replays whole groups until the buffer wraps, so a timed region that
+        starts here contains no eager remainder iterations (bench.py)."""
+        self.flush()
+        self._slot_ctr.zero_()
+        self._draw_pos = 0
+
     def flush(self):
         """Run the iterations that ``step`` has queued for a multi-iteration graph but not yet replayed."""
         if self._graph_pending:
@@ -398,8 +406,8 @@ class GraspStepper:
         if fork and self._side is None:
             self._side = torch.cuda.Stream()
         s = torch.cuda.Stream()
+        self.draw()  # may refill the draw buffers on the current stream: order it before the side stream's warm-up
         s.wait_stream(torch.cuda.current_stream())
-        self.draw()
         with torch.cuda.stream(s):
             self._iteration(_C.stream_ptr(), fork=fork, fused=fused)
         torch.cuda.current_stream().wait_stream(s)

@@ -69,6 +69,14 @@ int gq_lsq_boxqp_forward(const float* A, const float* b, const float* lower, con
                          void* workspace, size_t workspace_bytes, void* stream);
 int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, const float* grad_x, int64_t batch,
                           int m, int nz, float ridge, float* dx, float* dlam, void* stream);
+/* qpth's batch-global stopping rule (qpth/solvers/pdipm/batch.py forward loop) on the (B, max_iter)
+ * tables of per-iteration residuals and mu that the forward kernels record: kstar[0] = index of the last iteration
+ * whose record counts, kstar[1] = *n_iter = kstar[0] + 1.  Stop at the first iteration where no row improved its
+ * running-best residual for `not_improved_lim` iterations in a row, or max_rows(best residual) < eps, or
+ * min_rows(mu) > 1e32; NaN residuals never improve a row.  The forward entry points call exactly this.            */
+int gq_boxqp_stop_rule(const float* resid /* (B,max_iter) */, const float* mu /* (B,max_iter) */, int64_t batch,
+                       int max_iter, float eps, int not_improved_lim, float* runmin_scratch /* (B) */,
+                       int32_t* kstar /* (2) */, int32_t* n_iter /* (1) or NULL */, void* stream);
 
 /* ---- force-closure energy: energy_fnc for energy_type "graspqp" ------------------------------------
  * reference: metrics/ops/span.py:263-295,313-415  metrics/ops/registry.py:31-89
@@ -230,7 +238,11 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (
                         uint64_t* span /* NULL, or {min start, max end} in 100 MHz device ticks, pre-set to {~0, 0} */,
                         void* stream);
 int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes);
-int gq_debug_set_pen_counters(uint64_t* counters /* device, 4 words, or NULL */);
+/* diagnostics (NULL = off): 8 device words.  Stand-alone gq_hand_pen_forward (penetration_only = 1) adds [4] (point,
+ * link) pairs that reach candidate evaluation, [5] executed point-triangle rankings, [6] pairs ranked inline because the
+ * block's LDS lists were full, [7] blocks; gq_sdf_forward_meshset adds [0] 64-face cluster visits, [1] queries, sets
+ * [2] = max visits of a query, adds [3] queries with > 16 visits.  Not read by the fused launches.                  */
+int gq_debug_set_pen_counters(uint64_t* counters /* device, 8 words, or NULL */);
 /* grad_dis (B,P) = upstream d E / d dis.  grad_dis == NULL selects the fused E_pen form: the weights are
  * w_pen * [dis > 0] and e_pen (B) = sum_j relu(dis_j) is written as well (core/energy.py:59-61).
  * span / span_acc (optional): the 64 x {min start, max end} shards filled by gq_hand_pen_forward are folded into

@@ -100,7 +100,7 @@ def pdipm_forward(Q, p, G, h, eps=5e-2, maxIter=12, notImprovedLim=3, history=No
             for k, v in (("x", x), ("z", z), ("s", s)):
                 best[k] = torch.where(I[:, None], v, best[k])
         if history is not None:
-            history.append({"resids": resids.clone(), "x": x.clone(), "z": z.clone(), "s": s.clone()})
+            history.append({"resids": resids.clone(), "mu": mu.clone(), "x": x.clone(), "z": z.clone(), "s": s.clone()})
         if nNotImproved == notImprovedLim or bool(best["resids"].max() < eps) or bool(mu.min() > 1e32):
             return best["x"], best["z"], best["s"], it + 1
 
@@ -176,7 +176,7 @@ def pdipm_forward_box(Q, p, lower, upper, eps=5e-2, maxIter=12, notImprovedLim=3
             for k, v in (("x", x), ("z", z), ("s", s)):
                 best[k] = torch.where(I[:, None], v, best[k])
         if history is not None:
-            history.append({"resids": resids.clone(), "x": x.clone(), "z": z.clone(), "s": s.clone()})
+            history.append({"resids": resids.clone(), "mu": mu.clone(), "x": x.clone(), "z": z.clone(), "s": s.clone()})
         if nNotImproved == notImprovedLim or bool(best["resids"].max() < eps) or bool(mu.min() > 1e32):
             return best["x"], best["z"], best["s"], it + 1
         dx_a, ds_a, dz_a = _solve_kkt_box(Q, d, rx, rs, rz)
@@ -194,9 +194,38 @@ def pdipm_forward_box(Q, p, lower, upper, eps=5e-2, maxIter=12, notImprovedLim=3
     return best["x"], best["z"], best["s"], it + 1
 
 
+def stop_rule(resid, mu, eps=5e-2, notImprovedLim=3):
+    """qpth's batch-global stopping rule replayed on the (B, maxIter) tables of per-iteration residuals / mu
+    (the loop head of ``pdipm_forward`` above: best-tracking, nNotImproved, the three stop conditions).
+
+    -> (k_star, best_iter): k_star = index of the iteration at which the batch stops (n_iter = k_star + 1; maxIter - 1 if
+    no condition fires), best_iter (B,) = each row's best iteration among 0..k_star (first strict minimum; an iterate
+    with a NaN residual never replaces the best)."""
+    resid = torch.as_tensor(resid)
+    mu = torch.as_tensor(mu)
+    B, T = resid.shape
+    best = resid[:, 0].clone()
+    bi = torch.zeros(B, dtype=torch.long)
+    n_not = 0
+    k_star = T - 1
+    for it in range(T):
+        if it > 0:
+            I = resid[:, it] < best
+            n_not = 0 if bool(I.any()) else n_not + 1
+            best = torch.where(I, resid[:, it], best)
+            bi = torch.where(I, torch.full_like(bi, it), bi)
+        if n_not == notImprovedLim or bool(best.max() < eps) or bool(mu[:, it].min() > 1e32):
+            k_star = it
+            break
+    return k_star, bi
+
+
 # --------------------------------------------------------------------------------------------------
 # autograd function with qpth's implicit backward
 # --------------------------------------------------------------------------------------------------
+LAST = {"n_iter": None}  # iteration count of the most recent forward (tests compare it with the HIP kernels')
+
+
 class _QPFunctionFn(torch.autograd.Function):
     """x = argmin QP;  backward = one KKT solve at the returned (x, lam, slack)  (qpth/qp.py backward).
 
@@ -214,6 +243,8 @@ class _QPFunctionFn(torch.autograd.Function):
             x, lam, slack, nit = pdipm_forward(Qd, pd, G.detach(), hd, eps, maxIter)
         ctx.save_for_backward(x, lam, slack, Qd, G.detach())
         ctx.n_iter = nit
+        ctx.box_form = bool(box_form)
+        LAST["n_iter"] = nit
         return x
 
     @staticmethod
@@ -224,6 +255,11 @@ class _QPFunctionFn(torch.autograd.Function):
             G = G.unsqueeze(0).expand(B, -1, -1)
         m = G.shape[1]
         d = torch.clamp(lam, min=1e-8) / torch.clamp(slack, min=1e-8)
+        if ctx.box_form:  # the same KKT solve in the reduced nz x nz form (large batches: no (B, 2nz, 2nz) tensors)
+            z0 = torch.zeros(B, 2 * nz, dtype=Q.dtype)
+            dx, _, dlam = _solve_kkt_box(Q, d, dl_dx, z0, z0)
+            dQ = 0.5 * (dx.unsqueeze(2) * x.unsqueeze(1) + x.unsqueeze(2) * dx.unsqueeze(1))
+            return dQ, dx, None, -dlam, None, None, None
         R = G @ torch.linalg.solve(Q, G.transpose(1, 2))
         S = R + torch.diag_embed(1.0 / d)
         z0 = torch.zeros(B, m, dtype=Q.dtype)

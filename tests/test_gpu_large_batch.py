@@ -1,0 +1,316 @@
+"""GPU parity at the batch sizes of BASELINE configs 3 / 4 / 5 (per rank), which take a different launch sequence than
+config 2: for more than 512 rows the contact queries of the object SDF get their own launch (gq_sdf_forward_meshset
+instead of riding in the FK block), above 256 rows qpth's batch-global stop rule runs as a launch of its own (one
+wavefront up to 1024 rows, the tiled 1024-thread kernel above), and nz = 96 (8-edge cones) puts two QP columns on a lane.
+
+Also here: the stop rule itself on arbitrary residual tables (bit-exact against oracle/ref_cpu/qp.py::stop_rule, with the
+deciding row in the LAST tile), a heterogeneous >= 3000-row QP batch against the oracle's PDIPM, and a scene that
+overflows the LDS item list of the hand-penetration query on purpose.  Tolerances: tests/test_gpu_parity.py header."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ref_cpu  # noqa: E402
+from ref_cpu import models as omodels  # noqa: E402
+from ref_cpu import qp as oqp  # noqa: E402
+from ref_cpu import span as ospan  # noqa: E402
+
+from _scenes import hetero_contacts  # noqa: E402
+from graspqp_amd.hands import get_hand_spec  # noqa: E402
+from graspqp_amd.utils import meshes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gq():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graspqp_amd import _C, ops, stepper
+
+    _C.lib()
+    return type("gq", (), {"ops": ops, "C": _C, "stepper": stepper})
+
+
+def _rel(a, b, floor=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole iteration at 2048 / 4096 / 8192 rows
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hand_name,n,k,n_obj,be", [
+    ("allegro", 12, 4, 8, 256),       # BASELINE configs[3] per rank: 8 meshes x 256 = 2048 rows
+    ("shadow_hand", 16, 4, 8, 512),   # configs[2]: 8 meshes x 512 = 4096 rows, nz = 64
+    ("robotiq3", 12, 8, 8, 1024),     # configs[4] share: 8 meshes x 1024 = 8192 rows, 8-edge cones, nz = 96
+])
+def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
+    from bench import make_initial_state
+
+    spec = get_hand_spec(hand_name)
+    fvs = [meshes.superquadric(o) for o in range(n_obj)]  # the bench's meshes (9024 faces each)
+    sps = [meshes.surface_points(f, 2500, oversample=4, seed=42) for f in fvs]
+    B = n_obj * be
+    hand = gq.ops.HandHandle(spec)
+    ms = gq.ops.MeshSet(fvs)
+    surf = torch.tensor(np.stack(sps))
+    hps, idxs = zip(*[make_initial_state(spec, f, be, n, 1000 + o) for o, f in enumerate(fvs)])
+    hp, idx = torch.cat(hps).cuda(), torch.cat(idxs).cuda()
+    # a few rows pushed into their object so that E_pen and the inside branch of E_dis are non-trivial
+    hp[::97, :3] *= 0.45
+    fc_cfg = {"n_cone_vecs": k}
+
+    # (a) captured graph of the fused launches == eager unfused launches, bit for bit, over several iterations
+    outs = []
+    for rep in range(2):
+        s = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg, seed=5)
+        s.reset(hp, idx)
+        if rep == 1:
+            s.capture(iters=2)
+        for _ in range(4):
+            s.step()
+        s.flush()
+        torch.cuda.synchronize()
+        outs.append((s.energy.clone(), s.hand_pose.clone(), s.contact_idx.clone(), s.grad.clone(), s.terms.clone()))
+        assert int(s.n_iter.item()) >= 1
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][3]).all()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), "hipGraph replay of the fused launches differs from the eager unfused launches"
+    pose, cidx = outs[0][1], outs[0][2]  # accepted state after four iterations: a mix of moved and unmoved rows
+
+    # (b) E_fc and its contact-point gradient of the WHOLE batch against the oracle's metric (fp64) run on the same
+    # B x n contact points / object normals: identical batch composition, so qpth's batch-global stop rule sees the
+    # same rows (1e-4 median / 5e-3 max, gradient 2e-2 norm-wise, n_iter equal)
+    st = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg,
+                                 weights={"E_dis": 0.0, "E_fc": 1.0, "E_pen": 0.0, "E_spen": 0.0, "E_joints": 0.0})
+    t_fc, _, _ = st.evaluate(pose, cidx)
+    torch.cuda.synchronize()
+    po = st.cpts.cpu().double().requires_grad_()
+    eo, _ = ospan.e_fc(po, st.obj_normal.cpu().double(), st.cog.cpu().double(), k=k, box_form=True)
+    n_iter_o = oqp.LAST["n_iter"]
+    eo.sum().backward()
+    rel = _rel(t_fc["E_fc"].cpu().numpy(), eo.detach().numpy())
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert int(st.n_iter.item()) == n_iter_o, (int(st.n_iter.item()), n_iter_o)
+    gfc = np.linalg.norm(st.g_cpts.cpu().numpy() - po.grad.numpy()) / np.linalg.norm(po.grad.numpy())
+    assert gfc < 2e-2, gfc
+
+    # (c) a sample of rows, one per third of the batch, against the fp64 oracle: the four other terms and the gradient
+    # of their weighted sum (E_fc's stop rule depends on the batch: checked in (b))
+    w0 = {"E_dis": 100.0, "E_fc": 0.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    s3 = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg, weights=w0)
+    t3, _, g3 = s3.evaluate(pose, cidx)
+    torch.cuda.synchronize()
+    assert (t3["E_pen"] > 0).sum() > 0, "scene must contain penetrating rows"
+    pen_rows = torch.nonzero(t3["E_pen"] > 1e-4).flatten().tolist()
+    rows = sorted({0, B // 2 + 1, B - 1, pen_rows[0], pen_rows[-1]})
+    oh = omodels.OracleHand(spec, torch.float64)
+    for r in rows:
+        o = r // be
+        oo = omodels.OracleObject([fvs[o]], [sps[o]], 1, torch.float64)
+        hpo = pose[r : r + 1].cpu().double().requires_grad_()
+        oh.set_parameters(hpo, cidx[r : r + 1].cpu())
+        lo = ref_cpu.calculate_energy(oh, oo, box_form=True, k=k)
+        for kk in ("E_dis", "E_pen", "E_spen", "E_joints"):
+            np.testing.assert_allclose(t3[kk][r].item(), lo[kk].item(), rtol=3e-4, atol=3e-6, err_msg=f"{kk} row {r}")
+        sum(w0[kk] * lo[kk] for kk in w0 if w0[kk] != 0.0).sum().backward()
+        go = oh.hand_pose.grad.numpy()[0]
+        gerr = np.linalg.norm(g3[r].cpu().numpy() - go) / np.linalg.norm(go)
+        assert gerr < 2e-3, (r, gerr)
+
+    # (d) the stepper's fused evaluation == the autograd route built from the C-ABI building blocks (2048-row case only:
+    # the class surface materialises (B,P,3) tensors like the reference does)
+    if B <= 2048:
+        from graspqp_amd.core.energy import calculate_energy
+        from graspqp_amd.core.hand_model import HandModel
+        from graspqp_amd.core.object_model import ObjectModel
+        from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+        W = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+        s4 = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg)
+        t4, tot4, g4 = s4.evaluate(pose, cidx)
+        hm = HandModel(spec, "cuda")
+        om = ObjectModel(batch_size_each=be, num_samples=2500)
+        om.initialize_from_meshes(fvs, surface_points_list=sps)
+        hm.set_parameters(pose.clone().requires_grad_(), cidx)
+        fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": k})
+        losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=list(W), svd_gain=0.1)
+        tot = sum(W[kk] * v for kk, v in losses.items())
+        tot.sum().backward()
+        for kk in W:
+            np.testing.assert_allclose(t4[kk].cpu().numpy(), losses[kk].detach().cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=kk)
+        assert (hm.hand_pose.grad - g4).norm() <= 2e-3 * g4.norm()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# qpth's batch-global stop rule
+# ---------------------------------------------------------------------------------------------------------------
+def _gpu_stop(gq, resid, mu, eps, lim):
+    B, T = resid.shape
+    r, m = resid.float().contiguous().cuda(), mu.float().contiguous().cuda()
+    scratch = torch.empty(B, device="cuda")
+    ks = torch.full((2,), -7, dtype=torch.int32, device="cuda")
+    nit = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+    gq.C.call("gq_boxqp_stop_rule", gq.C.f32(r), gq.C.f32(m), ctypes.c_int64(B), T, float(eps), int(lim),
+              gq.C.f32(scratch), gq.C.i32(ks), gq.C.i32(nit), gq.C.stream_ptr())
+    torch.cuda.synchronize()
+    return ks.tolist(), int(nit.item())
+
+
+@pytest.mark.parametrize("B", [64, 700, 1024, 1025, 3000, 5000])
+@pytest.mark.parametrize("T", [12, 20])  # > 16 iterations: the generic kernel
+def test_stop_rule_kernels_on_tables(gq, B, T):
+    """Every stop condition with its deciding row in the LAST 1024-row tile (a kernel that looks at the first tile, or at
+    any periodic subset, stops at a different iteration), NaN residuals, and random tables -- bit-exact against the
+    oracle's restatement of the rule evaluated on the same fp32 tables."""
+    g = torch.Generator().manual_seed(B * 31 + T)
+    eps = 5e-2
+    last = B - 1 - int(torch.randint(0, min(300, B - 1024 * ((B - 1) // 1024)), (1,), generator=g))  # a row of the last tile
+    cases = {}
+    # 1) eps rule: every row is below eps from iteration 3 on, the deciding row only from iteration 8 on
+    r = torch.rand(B, T, generator=g) * 0.01 + 1e-3
+    r[:, :3] += 1.0
+    r[last, :8] = 0.9 - 0.01 * torch.arange(8.0)
+    cases["eps"] = (r, torch.ones(B, T), eps, 3, 8)
+    # 2) not-improved rule: all rows stop improving after iteration 2 except the deciding row, which improves until 6
+    r = torch.ones(B, T)
+    r[:, 1] = 0.9
+    r[:, 2] = 0.8
+    r[:, 3:] = 0.8 + 0.05 * torch.rand(B, T - 3, generator=g)
+    r[last, :7] = 2.0 - 0.1 * torch.arange(7.0)
+    r[last, 7:] = 1.5
+    cases["not_improved"] = (r, torch.ones(B, T), 1e-6, 3, 9)
+    # 3) mu rule: every mu explodes at iteration 4 except the deciding row's, which does so at iteration 7 (residuals
+    # keep improving, so the other rules never fire)
+    r = (2.0 - 0.05 * torch.arange(float(T)))[None].repeat(B, 1) + torch.rand(B, 1, generator=g)
+    m = torch.ones(B, T)
+    m[:, 4:] = 3e33
+    m[last, 4:7] = 5.0
+    cases["mu"] = (r, m, 1e-6, 3, 7)
+    # 4) NaN never improves: from iteration 2 on every row but the deciding one produces NaN residuals; the deciding row
+    # improves until iteration 6
+    r = torch.ones(B, T)
+    r[:, 1] = 0.5
+    r[:, 2:] = float("nan")
+    r[last, 2:7] = torch.tensor([0.4, 0.3, 0.2, 0.1, 0.05])
+    r[last, 7:] = 0.3
+    cases["nan"] = (r, torch.ones(B, T), 1e-6, 3, 9)
+    for name, (r, m, e, lim, want) in cases.items():
+        ks_o, _ = oqp.stop_rule(r.float(), m.float(), e, lim)
+        assert ks_o == want, (name, ks_o, want)  # the scenario does what it says
+        if B > 1024:  # ... and would be decided differently without the last tile
+            ks_first, _ = oqp.stop_rule(r[:1024].float(), m[:1024].float(), e, lim)
+            assert ks_first != ks_o, name
+        ks, nit = _gpu_stop(gq, r, m, e, lim)
+        assert ks == [ks_o, ks_o + 1] and nit == ks_o + 1, (name, B, T, ks, ks_o)
+    # 5) random tables with NaNs sprinkled in
+    for trial in range(4):
+        r = torch.rand(B, T, generator=g) * torch.logspace(0, -3, T)[None]
+        r[torch.rand(B, T, generator=g) < 0.02] = float("nan")
+        m = torch.rand(B, T, generator=g)
+        e = [5e-2, 1e-2, 1e-3, 2e-1][trial]
+        ks_o, _ = oqp.stop_rule(r.float(), m.float(), e, 3)
+        ks, nit = _gpu_stop(gq, r, m, e, 3)
+        assert ks[0] == ks_o and nit == ks_o + 1, ("random", trial, B, T, ks, ks_o)
+
+
+@pytest.mark.parametrize("n,k,B", [(12, 4, 3072), (4, 4, 5000)])
+def test_qp_heterogeneous_batch_deciding_row_in_last_tile(gq, n, k, B):
+    """A heterogeneous batch (rows converge after 4 .. 10 PDIPM iterations) arranged so that the slowest rows -- the ones
+    that decide the batch-global stop iteration -- sit in the last 1024-row tile: n_iter and x against the oracle's
+    PDIPM (fp64) on the same batch."""
+    pts, nrm, cog = hetero_contacts(B + B // 2, n, 11)
+    F = ospan.grasp_matrix(pts, nrm, cog, 0.2, k)
+    nz = F.shape[-1]
+    Q = F.transpose(1, 2) @ F + 1e-4 * torch.eye(nz, dtype=F.dtype)
+    Bc = F.shape[0]
+    lo, hi = torch.ones(Bc, nz, dtype=F.dtype), 21 * torch.ones(Bc, nz, dtype=F.dtype)
+    full = []
+    oqp.pdipm_forward_box(Q, torch.zeros(Bc, nz, dtype=F.dtype), lo, hi, eps=-1.0, notImprovedLim=99, history=full)
+    resid = torch.stack([h["resids"] for h in full], 1)
+    runbest = torch.cummin(torch.nan_to_num(resid, nan=float("inf")), 1)[0]  # a NaN iterate never becomes best
+    eps = 5e-2
+    # target stop iteration ks: every kept row is clearly below eps at ks; the "deciders" are clearly above eps at ks - 1,
+    # all other rows clearly below (25 % margins: the comparison is about the rule, not about fp32-vs-fp64 round-off of
+    # a residual that passes eps by a hair)
+    for ks in range(11, 3, -1):
+        ok = (torch.isfinite(resid[:, : ks + 1]).all(1) & (runbest[:, ks] < 0.75 * eps)
+              & ((runbest[:, ks - 1] < 0.75 * eps) | (runbest[:, ks - 1] > 1.25 * eps)))
+        dec = ok & (runbest[:, ks - 1] > 1.25 * eps)
+        if ok.sum() >= B and dec.sum() >= 1:
+            break
+    else:
+        raise AssertionError("no feasible stop iteration in the synthetic batch")
+    easy, decid = torch.nonzero(ok & ~dec).flatten(), torch.nonzero(dec).flatten()[:64]
+    order = torch.cat([easy[: B - decid.numel()], decid])  # the deciding rows close the batch: last 1024-row tile
+    assert order.numel() == B
+    Fb = F[order].contiguous()
+    b0 = torch.zeros(B, 6, dtype=F.dtype)
+    val_o, x_o = oqp.lsq_box_qp(Fb, b0, 1.0, 21.0, box_form=True)
+    n_iter_o = oqp.LAST["n_iter"]
+    assert n_iter_o == ks + 1
+    oqp.lsq_box_qp(Fb[:1024], b0[:1024], 1.0, 21.0, box_form=True)
+    assert oqp.LAST["n_iter"] < n_iter_o, "the first tile alone must stop earlier (or the test cannot fail)"
+    Fg = Fb.float().cuda().requires_grad_()
+    x = gq.ops.lsq_box_qp(Fg, None, 1.0, 21.0)
+    torch.cuda.synchronize()
+    assert int(x.grad_fn.n_iter.item()) == n_iter_o, (int(x.grad_fn.n_iter.item()), n_iter_o)
+    val = 0.5 * ((Fg @ x.unsqueeze(-1)).squeeze(-1) ** 2).sum(-1)
+    rel = _rel(2 * (val.detach().cpu().numpy() + 0.01), 2 * (val_o.numpy() + 0.01))
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert np.abs(x.detach().cpu().numpy() - x_o.numpy()).max() < 5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hand-penetration query: LDS capacity overflow on purpose
+# ---------------------------------------------------------------------------------------------------------------
+def test_hand_penetration_item_list_overflow(gq):
+    """A tiny dense object placed inside an Allegro fingertip: each of the 256 surface points of a block lies deep inside
+    the link, where a voxel's candidate list holds ~100 faces -> ~25 000 items against GQ_PG_ICAP = 4096, so most
+    entries of every block are ranked inline and part of the reserved item slots stay unused (the path whose
+    uninitialised-slot bug was fixed in round 1).  The result must equal the exact query (penetration_only = 0)."""
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+
+    spec = get_hand_spec("allegro")
+    link = 3  # fingertip mesh, 342 faces
+    P, be = 1024, 3
+    fv = meshes.icosphere(3, 0.004)
+    sp = meshes.surface_points(fv, P, oversample=4, seed=1)
+    th = torch.tensor(spec.default_state, dtype=torch.float64)[None].repeat(be, 1)
+    th[1] += 0.2
+    th[2] -= 0.1
+    oh = omodels.OracleHand(spec, torch.float64)
+    hp = torch.cat([torch.zeros(be, 3, dtype=torch.float64), torch.tensor([[1.0, 0, 0, 0, 1, 0]], dtype=torch.float64).repeat(be, 1), th], 1)
+    oh.set_parameters(hp, torch.zeros(be, 4, dtype=torch.long))
+    lf = spec.link_faces(link).reshape(-1, 3)
+    c = torch.tensor(0.5 * (lf.min(0) + lf.max(0)), dtype=torch.float64)
+    T = oh.current_status[:, link]
+    hp[:, :3] = -(T[:, :3, :3] @ c + T[:, :3, 3])  # global rotation = identity: the link centre lands on the object
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=P)
+    om.initialize_from_meshes([fv], surface_points_list=[sp])
+    hm.set_parameters(hp.float().cuda(), torch.zeros(be, 4, dtype=torch.long).cuda())
+    dis0 = hm.cal_distance(om.surface_points_each, penetration_only=0)
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    gq.C.call("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
+    try:
+        dis1 = hm.cal_distance(om.surface_points_each, penetration_only=1)
+        torch.cuda.synchronize()
+    finally:
+        gq.C.call("gq_debug_set_pen_counters", None)
+    entries, rankings, inline, blocks = (int(v) for v in cnt[4:8])
+    assert blocks == be * (P // 256)
+    assert rankings > 4096 * blocks and inline > 0.5 * entries, (entries, rankings, inline, blocks)
+    pos = dis0 > 1e-6
+    assert pos.float().mean() > 0.9, "the object must sit inside the link"
+    torch.testing.assert_close(dis1[pos], dis0[pos], rtol=2e-4, atol=3e-6)
+    assert (dis1[dis0 <= -1e-6] <= 0).all()
+    # against the fp64 oracle as well
+    oh.set_parameters(hp, torch.zeros(be, 4, dtype=torch.long))
+    oo = omodels.OracleObject([fv], [sp], be, torch.float64)
+    do = oh.cal_distance(oo.surface_points_tensor).numpy()
+    big = np.abs(dis1.cpu().numpy() - do)[do > 1e-6] > 3e-6
+    assert big.mean() < 2e-3, big.mean()

@@ -10,6 +10,12 @@ from scipy.optimize import lsq_linear
 import ref_cpu
 from ref_cpu import mala, models, qp, span
 from graspqp_amd.hands import get_hand_spec
+from _scenes import hetero_contacts
+
+
+def _hetero_F(B, n, k, seed):
+    pts, nrm, cog = hetero_contacts(B, n, seed)
+    return span.grasp_matrix(pts, nrm, cog, 0.2, k), pts, nrm, cog
 
 W = ref_cpu.energy.DEFAULT_WEIGHTS
 
@@ -122,3 +128,44 @@ def test_mala_loop_matches_reference_optimizer(golden_dir):
         gref = g[f"s{s}_grad"]
         assert np.linalg.norm(grad.numpy() - gref) <= 1e-5 * np.linalg.norm(gref)
         np.testing.assert_allclose(ema.numpy(), g[f"s{s}_ema"], rtol=1e-5, atol=1e-9)
+
+
+def test_stop_rule_restatement_equals_the_forward_loop():
+    """ref_cpu.qp.stop_rule (what the GPU stop kernels are checked against) replays exactly the decisions the PDIPM loop
+    takes, for each of its stop conditions, and NaN residuals never become best."""
+    F, *_ = _hetero_F(96, 4, 4, 0)
+    B, _, nz = F.shape
+    Q = F.transpose(1, 2) @ F + 1e-4 * torch.eye(nz, dtype=F.dtype)
+    p = torch.zeros(B, nz, dtype=F.dtype)
+    lo, hi = torch.ones(B, nz, dtype=F.dtype), 21 * torch.ones(B, nz, dtype=F.dtype)
+    full = []
+    qp.pdipm_forward_box(Q, p, lo, hi, eps=-1.0, notImprovedLim=99, history=full)  # never stops: all 12 iterations
+    resid = torch.stack([h["resids"] for h in full], 1)
+    mu = torch.stack([h["mu"] for h in full], 1)
+    for eps, lim in ((5e-2, 3), (1e-9, 3), (1e-9, 1), (0.5, 3)):
+        x, lam, s, nit = qp.pdipm_forward_box(Q, p, lo, hi, eps=eps, notImprovedLim=lim)
+        ks, bi = qp.stop_rule(resid, mu, eps, lim)
+        assert ks + 1 == nit, (eps, lim, ks, nit)
+        xb = torch.stack([full[int(bi[r])]["x"][r] for r in range(B)])
+        assert torch.equal(xb, x)
+    # synthetic tables: NaN handling and the mu rule
+    r = torch.tensor([[1.0, 0.5, float("nan"), 0.2], [1.0, float("nan"), 0.9, 0.01]])
+    m = torch.tensor([[1.0, 1.0, 1.0, 1.0], [1.0, 1.0, 1.0, 1.0]])
+    ks, bi = qp.stop_rule(r, m, 0.3, 3)
+    assert ks == 3 and bi.tolist() == [3, 3]
+    ks, bi = qp.stop_rule(r, torch.tensor([[1.0, 2e32, 1.0, 1.0], [1.0, 3e32, 1.0, 1.0]]), 1e-9, 3)
+    assert ks == 1 and bi.tolist() == [1, 0]
+    ks, _ = qp.stop_rule(torch.tensor([[float("nan"), 0.0, 0.0], [1.0, 0.0, 0.0]]), torch.ones(2, 3), 0.5, 3)
+    assert ks == 2  # a row whose first residual is NaN keeps the batch maximum NaN: the eps rule never fires
+
+
+def test_box_form_backward_equals_qpth_block_form():
+    F, *_ = _hetero_F(24, 4, 4, 1)
+    b = torch.zeros(24, 6, dtype=F.dtype)
+    grads = []
+    for box in (False, True):
+        Fr = F.clone().requires_grad_()
+        v, _ = qp.lsq_box_qp(Fr, b, 1.0, 21.0, box_form=box)
+        v.sum().backward()
+        grads.append(Fr.grad)
+    assert (grads[0] - grads[1]).abs().max() <= 1e-8 * grads[0].abs().max()

@@ -59,3 +59,32 @@ def test_gather_results_two_ranks_gloo():
     assert pose0 == [0.0] * 4 + [1.0] * 4 + [2.0] * 4
     assert idx0 == [0] * 4 + [1] * 4 + [2] * 4
     assert energy == [o * 10.0 + i for o in range(3) for i in range(4)]
+
+
+def _bench(*flags, env=None):
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], env=e, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` launches two ranks itself (the parent touches no GPU); their rendezvous, barrier-
+    bracketed window, MAX over ranks and end-of-run gather run here over gloo (--selftest_ranks: no GPU work)."""
+    import json
+
+    r = _bench("--gpus", "2", "--dist_backend", "gloo", "--selftest_ranks", "--n_objects", "3", "--batch_size", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["objects_per_rank"] == [3, 3] and out["rows_gathered"] == 2 * 3 * 4
+    assert out["window_s_max_over_ranks"] >= 0.02  # the slower rank (rank 1 sleeps 20 ms) sets the window
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench("--gpus", "2", "--selftest_ranks", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

@@ -91,7 +91,9 @@ class HandModel:
             self.contact_point_indices = contact_point_indices.clone()
         else:
             self.contact_point_indices = torch.where(env_mask.unsqueeze(-1), contact_point_indices, self.contact_point_indices)
-        Rg, LT, cp, cn, sc, ws = ops.fk_contacts(self.hand_pose, self.contact_point_indices, self._hand)
+        # reference hand_model.py:815-831: the contact points are gathered with the indices PASSED IN, also for the rows
+        # outside env_mask (whose stored indices stay what they were) -- kept, it decides the energies of a reset iteration
+        Rg, LT, cp, cn, sc, ws = ops.fk_contacts(self.hand_pose, contact_point_indices.contiguous(), self._hand)
         self._fk_ws = ws
         self.global_rotation = Rg
         self.current_status = LT

@@ -33,6 +33,11 @@ class MalaStar:
         self.old_contact_point_indices = None
         self.old_grad_hand_pose = None
         self.last_draws = None
+        # reference quirk after a re-initialisation (set_parameters(env_mask=...) makes hand_pose a leaf, hand_model.py:
+        # 846-851): in the NEXT iteration autograd accumulates the new gradient in place into the tensor kept as
+        # old_grad_hand_pose, so rejected rows get old + new gradient back (pinned by tests/golden/mala_ext_*.npz)
+        self._leaf_pose_pending = False
+        self._old_grad_accumulates = False
 
     def _draw(self, B, n):
         g = self.generator
@@ -61,6 +66,7 @@ class MalaStar:
         self.old_hand_pose = hp
         self.old_contact_point_indices = idx
         self.old_grad_hand_pose = grad
+        self._old_grad_accumulates, self._leaf_pose_pending = self._leaf_pose_pending, False
         hm.set_parameters(pose_out.requires_grad_(), idx_out)
         return s
 
@@ -70,6 +76,7 @@ class MalaStar:
         self.old_hand_pose[mask] = self.hand_model.hand_pose.detach()[mask]
         self.old_contact_point_indices[mask] = self.hand_model.contact_point_indices[mask]
         self.old_grad_hand_pose[mask] = 0 * self.old_grad_hand_pose[mask]
+        self._leaf_pose_pending = True
 
     def accept_step(self, energy, new_energy, reset_mask=None, z_score=None, z_score_threshold=2.0, u_accept=None):
         """Returns (accept (B,) bool, temperature (B,)).  ``energy`` is updated in place for accepted rows
@@ -87,6 +94,8 @@ class MalaStar:
         pose = self.old_hand_pose.clone()
         idx = self.old_contact_point_indices.clone()
         grad = self.old_grad_hand_pose.clone()
+        if self._old_grad_accumulates:
+            grad += grad_new
         accept = torch.empty(B, dtype=torch.uint8, device=self.device)
         T = torch.empty(B, device=self.device)
         rm = None if reset_mask is None else reset_mask.to(torch.uint8).contiguous()

@@ -92,6 +92,7 @@ class GraspStepper:
             self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)
             self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)
         self._graph, self._graph_iters, self._graph_pending = None, 1, 0
+        self._after_reset = False
         self.kernel_events = None
         self._span = torch.zeros(64, 2, dtype=torch.int64, device=self.dev)
         self._span[:, 0] = -1  # {~0, 0}: armed
@@ -319,6 +320,8 @@ class GraspStepper:
 
     def step(self, draws=None):
         """One MALA* iteration.  ``draws`` = (u_switch, new_idx, u_accept) to inject random numbers (tests)."""
+        if self._after_reset:
+            return self._step_after_reset(draws)
         if self._graph_pending and self._draw_pos == 0:
             self.flush()  # queued iterations still need the draws that the refill below would overwrite
         self.draw(draws)
@@ -343,10 +346,27 @@ class GraspStepper:
                 self.kernel_events.append(timer)
             self._iteration(st, timer=timer)
 
+    def _step_after_reset(self, draws=None):
+        """The iteration that follows a re-initialisation.  Reference quirk: HandModel.set_parameters(env_mask=...) makes
+        hand_pose a leaf tensor (hand_model.py:846-851), and in the next iteration autograd accumulates the new gradient
+        IN PLACE into that leaf's .grad -- the tensor MalaStar keeps as old_grad_hand_pose (optimizer.py:266) -- so the
+        rows rejected in that iteration get old + new gradient back (optimizer.py:333-338).  Launched eagerly with the
+        stand-alone propose / accept kernels; pinned by tests/golden/mala_ext_*.npz."""
+        self.flush()
+        self.draw(draws)
+        st = _C.stream_ptr()
+        self._propose(st)
+        self._evaluate(self.pose_new, self.idx_new, st)
+        self._accept(st)
+        rej = (self.accept == 0).unsqueeze(1)
+        self.grad.add_(torch.where(rej, self.grad_new, torch.zeros_like(self.grad_new)))
+        self._slot_ctr += 1
+        self._after_reset = False
+
     def step_reset(self, reset_mask, new_pose, new_idx, draws=None):
         """One iteration of fit.py:399-458 in which the rows of ``reset_mask`` are re-initialised (fit.py:408-422): after
         the proposal their pose / contact indices are replaced by ``new_pose`` / ``new_idx`` (what the reference's
-        initialize_convex_hull writes; producing them is the caller's business), MalaStar.reset_envs zeroes their step
+        initialize_convex_hull writes, full batch size; see ``graspqp_amd.core.initializations``), MalaStar.reset_envs zeroes their step
         counter, gradient EMA and old gradient and makes the new pose the "old" one, and the accept step accepts them
         unconditionally.  Launched eagerly with the stand-alone propose / accept kernels (this happens every few hundred
         iterations); the device-side draw-slot counter is advanced by hand so that graph replays stay in step."""
@@ -355,14 +375,18 @@ class GraspStepper:
         st = _C.stream_ptr()
         m = reset_mask.to(self.dev, torch.bool)
         self._propose(st)
+        idx_all = new_idx.to(self.dev).contiguous()
         self.pose_new[m] = new_pose.to(self.dev, torch.float32)[m]
-        self.idx_new[m] = new_idx.to(self.dev)[m]
+        self.idx_new[m] = idx_all[m]
         self.step_count[m] = 0  # optimizer.py:275-284
         self.ema[m] = 0
         self.hand_pose[m] = self.pose_new[m]
         self.contact_idx[m] = self.idx_new[m]
         self.grad[m] = 0
-        self._evaluate(self.pose_new, self.idx_new, st)
+        # reference quirk (hand_model.py:815-831): set_parameters(..., env_mask) gathers the contact points of ALL rows with
+        # the freshly drawn indices it is handed (initializations.py:190-193), while the rows outside the mask keep
+        # their proposal's indices as state -- so this iteration's energies are evaluated at ``new_idx`` everywhere
+        self._evaluate(self.pose_new, idx_all, st)
         rm = m.to(torch.uint8).contiguous()
         B, D, n, mc = self.B, self.D, self.n, self.mala
         _C.call("gq_mala_accept", _C.f32(self.total_new), _C.f32(self._cur[2]), _C.f32(self.z), _C.u8(rm),
@@ -371,6 +395,7 @@ class GraspStepper:
                 _C.f32(self.energy), _C.f32(self.hand_pose), _C.i64(self.contact_idx), _C.f32(self.grad),
                 _C.u8(self.accept), _C.f32(self.temperature), 5, _C.f32(self.terms_new), _C.f32(self.terms), st)
         self._slot_ctr += 1
+        self._after_reset = True
 
     def realign_draws(self):
         """Run queued iterations, then restart the 64-slot buffer of random draws at slot 0 (the next ``step`` refills

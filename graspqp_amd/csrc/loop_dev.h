@@ -52,8 +52,8 @@ __device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row,
       const size_t o = (size_t)row * g.D + d;
       float gr = g.grad[o];
       if (g.clip) {
-        gr = fminf(fmaxf(gr, -100.0f), 100.0f);
-        if (gr != gr) gr = 0.0f;
+        // torch.clip keeps NaN (then zeroed, optimizer.py:211-213); fminf / fmaxf would turn it into a bound instead
+        gr = (gr != gr) ? 0.0f : fminf(fmaxf(gr, -100.0f), 100.0f);
       }
       float em = g.mu * g2[c] + (1.0f - g.mu) * g.ema[o];
       if (em != em) em = 0.0f;

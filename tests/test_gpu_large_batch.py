@@ -272,7 +272,7 @@ def test_qp_heterogeneous_batch_deciding_row_in_last_tile(gq, n, k, B):
 # ---------------------------------------------------------------------------------------------------------------
 def test_hand_penetration_item_list_overflow(gq):
     """A tiny dense object placed inside an Allegro fingertip: each of the 256 surface points of a block lies deep inside
-    the link, where a voxel's candidate list holds ~100 faces -> ~25 000 items against GQ_PG_ICAP = 4096, so most
+    the link, where a voxel's candidate list holds ~30 faces -> ~7 000 items against GQ_PG_ICAP = 4096, so many
     entries of every block are ranked inline and part of the reserved item slots stay unused (the path whose
     uninitialised-slot bug was fixed in round 1).  The result must equal the exact query (penetration_only = 0)."""
     from graspqp_amd.core.hand_model import HandModel
@@ -307,7 +307,7 @@ def test_hand_penetration_item_list_overflow(gq):
         gq.C.call("gq_debug_set_pen_counters", None)
     entries, rankings, inline, blocks = (int(v) for v in cnt[4:8])
     assert blocks == be * (P // 256)
-    assert rankings > 4096 * blocks and inline > 0.5 * entries, (entries, rankings, inline, blocks)
+    assert rankings > 4096 * blocks and inline > 0.2 * entries, (entries, rankings, inline, blocks)
     pos = dis0 > 1e-6
     assert pos.float().mean() > 0.9, "the object must sit inside the link"
     torch.testing.assert_close(dis1[pos], dis0[pos], rtol=2e-4, atol=3e-6)

@@ -25,7 +25,7 @@ class HandModel:
         self.n_contact_candidates = spec.n_contact_candidates
         self._actuated_joints_names = list(spec.joint_names)
         self.joints_names = list(spec.joint_names)
-        self._contact_links = None
+        self._contact_links = None  # reference hand_model.py:451: the grasp_type's link subset, None for the default type
         self.joints_lower = torch.tensor(spec.joints_lower, device=self.device)
         self.joints_upper = torch.tensor(spec.joints_upper, device=self.device)
         self.default_state = torch.tensor(spec.default_state, device=self.device)
@@ -123,6 +123,59 @@ class HandModel:
     # reference hand_model.py:989-1040
     def self_penetration(self):
         return ops.self_pen(self._sphere_centers, self._hand)
+
+    # reference hand_model.py:1220-1267: all C candidates (and normals) in the world frame
+    def get_contact_candidates(self, with_normals=False):
+        B = self.hand_pose.shape[0]
+        all_idx = torch.arange(self.n_contact_candidates, dtype=torch.long, device=self.device).unsqueeze(0).expand(B, -1)
+        _, _, cp, cn, _, _ = ops.fk_contacts(self.hand_pose.detach(), all_idx.contiguous(), self._hand)
+        return (cp, cn) if with_normals else cp
+
+    # reference hand_model.py:772-777 (HandModel.jacobian -> Chain.jacobian of the pytorch_kinematics fork): geometric
+    # Jacobian [J_v; J_w] of every mesh link, hand base frame, at the link-frame origin
+    def jacobian(self, joint_angles):
+        B = joint_angles.shape[0]
+        hp = torch.zeros(B, 9 + self.n_dofs, device=self.device)
+        hp[:, 3] = 1.0
+        hp[:, 7] = 1.0
+        hp[:, 9:] = joint_angles.detach()
+        idx = torch.zeros(B, 0, dtype=torch.long, device=self.device)
+        _, LT, _, _, _, ws = ops.fk_contacts(hp, idx, self._hand)
+        return ops.link_jacobian(self._hand, LT, ws)
+
+    # reference hand_model.py:1155-1218
+    def get_req_joint_velocities(self, moving_directions, contact_point_indices=None, coupled=True, return_ee_vel=False):
+        """Joint velocities that move the contact points along ``moving_directions`` (B,n,3, world frame): theta =
+        pinv(J) d with the linear contact Jacobian J_v + J_w x r and the damped pseudo-inverse (lambda = 1e-3).
+        -> (theta, residuals[, ee_vel]); coupled=False solves every contact on its own ((B,n,J), (B,n,3))."""
+        B = self.hand_pose.shape[0]
+        if contact_point_indices is None:
+            contact_point_indices = (torch.arange(self.n_contact_candidates, dtype=torch.long, device=self.device)
+                                     .unsqueeze(0).expand(B, -1))
+        idx = contact_point_indices.contiguous()
+        n = idx.shape[1]
+        # link transforms / joint frames of the CURRENT pose (written by the last set_parameters)
+        jc = ops.contact_jacobian(self._hand, idx, self.current_status, self._fk_ws)  # (B,n,3,J)
+        R = self.global_rotation.detach()
+        d = moving_directions.detach().to(torch.float32)
+        if coupled:
+            theta, res, ee = ops.joint_velocities(jc.reshape(B, 3 * n, self.n_dofs), d.reshape(B, 3 * n), R)
+            ee = ee.view(B, n, 3)
+        else:
+            theta, res, ee = ops.joint_velocities(jc.reshape(B * n, 3, self.n_dofs), d.reshape(B * n, 3),
+                                                  R.unsqueeze(1).expand(-1, n, -1, -1).reshape(B * n, 3, 3))
+            theta, res, ee = theta.view(B, n, self.n_dofs), res.view(B, n, 3), ee.view(B, n, 3)
+        if return_ee_vel:
+            return theta, res, ee
+        return theta, res
+
+    @property
+    def actuated_joints_names(self):
+        return self._actuated_joints_names
+
+    @property
+    def n_actutated_joints(self):  # (sic) reference hand_model.py:779-781
+        return self.n_dofs
 
 
 def get_hand_model(hand_name: str, device="cuda", asset_dir=None, **kwargs) -> HandModel:

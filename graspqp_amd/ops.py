@@ -391,6 +391,53 @@ def fk_contacts(hand_pose, idx, hand: HandHandle):
     return _FK.apply(hand_pose, idx, hand)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# export-time kinematics (scripts/fit.py:224-300): explicit Jacobians, damped pseudo-inverse, root pose
+# ----------------------------------------------------------------------------------------------------------
+def link_jacobian(hand: HandHandle, link_T, fk_workspace):
+    """(B,L,6,J) geometric Jacobian [J_v; J_w] of every mesh link in the hand frame (HandModel.jacobian)."""
+    LT = _c(link_T.detach())
+    B = LT.shape[0]
+    out = torch.empty(B, hand.L, 6, hand.J, device=LT.device)
+    _C.call("gq_link_jacobian", hand.handle, ctypes.c_int64(B), _C.f32(LT), _C.f32(out), _C.ptr(fk_workspace),
+            fk_workspace.numel(), _C.stream_ptr())
+    return out
+
+
+def contact_jacobian(hand: HandHandle, contact_idx, link_T, fk_workspace):
+    """(B,n,3,J) linear contact Jacobian J_v + J_w x r (hand_model.py:1176-1196), hand frame."""
+    LT = _c(link_T.detach())
+    ix = _c(contact_idx, torch.int64)
+    B, n = ix.shape
+    out = torch.empty(B, n, 3, hand.J, device=LT.device)
+    _C.call("gq_contact_jacobian", hand.handle, _C.i64(ix), ctypes.c_int64(B), n, _C.f32(LT), _C.f32(out),
+            _C.ptr(fk_workspace), fk_workspace.numel(), _C.stream_ptr())
+    return out
+
+
+def joint_velocities(jac, directions, Rg=None, damping=1e-3):
+    """theta = pinv_damped(J) d (hand_model.py:46-54,1198-1218).  jac (B,m,J), directions (B,m) -- world frame when
+    Rg (B,3,3) is given.  -> (theta (B,J), residual (B,m), ee_vel (B,m))."""
+    Jc = _c(jac.detach())
+    d = _c(directions.detach())
+    B, m, J = Jc.shape
+    theta = torch.empty(B, J, device=Jc.device)
+    res = torch.empty(B, m, device=Jc.device)
+    ee = torch.empty(B, m, device=Jc.device)
+    R = None if Rg is None else _c(Rg.detach()).reshape(B, 9)
+    _C.call("gq_joint_velocities", _C.f32(Jc), _C.f32(d), _C.f32(R), ctypes.c_int64(B), m, J, float(damping),
+            _C.f32(theta), _C.f32(res), _C.f32(ee), _C.stream_ptr())
+    return theta, res, ee
+
+
+def root_pose_wxyz(hand_pose):
+    """(B,7) = [translation, unit quaternion (w,x,y,z)] of hand_pose[:, :9] (fit.py:260-263)."""
+    hp = _c(hand_pose.detach())
+    out = torch.empty(hp.shape[0], 7, device=hp.device)
+    _C.call("gq_root_pose_wxyz", _C.f32(hp), ctypes.c_int64(hp.shape[0]), hp.shape[1], _C.f32(out), _C.stream_ptr())
+    return out
+
+
 class _HandPen(torch.autograd.Function):
     """max-over-links signed distance (inside positive) of object surface points; differentiable w.r.t. hand_pose.
 

@@ -221,6 +221,27 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
                    const gqAcceptDesc* accept /* NULL, or the Metropolis test on energy->total + state merge */,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- export-time kinematics: scripts/fit.py:224-300 (export_poses) --------------------------------------------
+ * Explicit geometric Jacobians in the hand frame.  `workspace` is the FK workspace written by gq_fk_forward for the
+ * same poses (it holds the per-joint frames), link_T the link transforms of that call.
+ * gq_link_jacobian: HandModel.jacobian (core/hand_model.py:772-777 -> the pytorch_kinematics fork's tree
+ *   Chain.jacobian): (B,L,6,J) = [J_v ; J_w] of every mesh link at its frame origin.
+ * gq_contact_jacobian: the linear contact Jacobian J_v + J_w x r of hand_model.py:1176-1196, (B,n,3,J).
+ * gq_joint_velocities: HandModel.get_req_joint_velocities (hand_model.py:1155-1218, coupled form): theta =
+ *   pinv(J) d with the damped pseudo-inverse of hand_model.py:46-54 (lambda = 1e-3 there), J (B,m,n_dofs) with m = 3 n,
+ *   directions (B,m) in the WORLD frame when Rg is given (they are rotated into the hand frame, :1166) else in the hand
+ *   frame; residual (B,m) = (J theta - d)^2, ee_vel (B,m) = J theta rotated back to the world frame.  n_dofs <= 64.
+ * gq_root_pose_wxyz: (B,7) = [t, unit quaternion w x y z] of hand_pose[:, :9] (fit.py:260-263).                    */
+int gq_link_jacobian(const gqHand* h, int64_t batch, const float* link_T /* (B,L,12) */, float* jac /* (B,L,6,J) */,
+                     const void* workspace, size_t workspace_bytes, void* stream);
+int gq_contact_jacobian(const gqHand* h, const int64_t* contact_idx /* (B,n) */, int64_t batch, int n_contact,
+                        const float* link_T, float* jac /* (B,n,3,J) */, const void* workspace, size_t workspace_bytes,
+                        void* stream);
+int gq_joint_velocities(const float* jac, const float* directions, const float* Rg /* (B,9) or NULL */, int64_t batch,
+                        int m, int n_dofs, float damping, float* theta /* (B,n_dofs) */, float* residual /* or NULL */,
+                        float* ee_vel /* or NULL */, void* stream);
+int gq_root_pose_wxyz(const float* hand_pose, int64_t batch, int pose_dim, float* root_pose /* (B,7) */, void* stream);
+
 /* ---- hand penetration: HandModel.cal_distance (E_pen) --------------------------------------------------
  * reference: core/hand_model.py:875-987, core/energy.py:57-62.  links = mesh set of the L link meshes.
  * dis (B,P) = max over links of sqrt(d^2 + 1e-8) * (-sign); link (B,P) argmax; gvec (B,P,3) = d dis / d x_h.

@@ -1,0 +1,173 @@
+"""GPU parity of the export path (reference scripts/fit.py:224-300): explicit Jacobians, damped pseudo-inverse joint
+velocities, root pose quaternion and the .dexgrasp.pt layout, against oracle/ref_cpu/export.py (fp64).  Tolerances:
+Jacobians 2e-6 abs (fp32 kinematics), joint velocities 1e-3 norm-wise (the normal equations are formed from an fp32
+Jacobian; the reference inverts them in fp32), quaternion 2e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ref_cpu import export as oexp  # noqa: E402
+from ref_cpu import kin as okin  # noqa: E402
+from ref_cpu import models as omodels  # noqa: E402
+
+from graspqp_amd.hands import get_hand_spec  # noqa: E402
+from graspqp_amd.utils import meshes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gq():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graspqp_amd import _C, ops
+
+    _C.lib()
+    return type("gq", (), {"ops": ops, "C": _C})
+
+
+def _pose(spec, B, seed, spread=0.12):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.nn.functional.normalize(torch.randn(B, 3, generator=g, dtype=torch.float64), dim=-1) * spread
+    six = torch.randn(B, 6, generator=g, dtype=torch.float64)
+    th = torch.tensor(spec.default_state, dtype=torch.float64)[None] + 0.3 * torch.randn(B, spec.n_dofs, generator=g, dtype=torch.float64)
+    return torch.cat([t, six, th], 1)
+
+
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3"])
+def test_explicit_jacobians(gq, hand_name):
+    from graspqp_amd.core.hand_model import HandModel
+
+    spec = get_hand_spec(hand_name)
+    B, n = 5, 12
+    hp = _pose(spec, B, 3)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(4))
+    hm = HandModel(spec, "cuda")
+    hpg = hp.float().cuda().requires_grad_()
+    hm.set_parameters(hpg, idx.cuda())
+    # link form: HandModel.jacobian
+    Jl = hm.jacobian(hpg[:, 9:])
+    Jl_o = oexp.link_jacobian(spec, hp[:, 9:])
+    assert Jl.shape == (B, spec.n_links, 6, spec.n_dofs)
+    np.testing.assert_allclose(Jl.cpu().numpy(), Jl_o.numpy(), atol=2e-6)
+    # contact form J_v + J_w x r, against the oracle's analytic form AND autograd through the oracle FK
+    Jc = gq.ops.contact_jacobian(hm._hand, idx.cuda(), hm.current_status, hm._fk_ws)
+    Jc_o = oexp.contact_jacobian(spec, hp[:, 9:], idx)
+    np.testing.assert_allclose(Jc.cpu().numpy(), Jc_o.numpy(), atol=2e-6)
+    Ja = torch.autograd.functional.jacobian(lambda t: oexp.contact_points_hand_frame(spec, t, idx), hp[:, 9:])
+    Ja = torch.stack([Ja[b, :, :, b, :] for b in range(B)])
+    np.testing.assert_allclose(Jc.cpu().numpy(), Ja.numpy(), atol=2e-6)
+    # ... and against the product's own analytic FK backward (the transposed form): d sum(w . cp_world) / d theta
+    w = torch.randn(B, n, 3, generator=torch.Generator().manual_seed(7))
+    (hm.contact_points * w.cuda()).sum().backward()
+    wh = (hm.global_rotation.detach().transpose(1, 2).unsqueeze(1) @ w.cuda().unsqueeze(-1)).squeeze(-1)  # R^T w
+    g_explicit = torch.einsum("bnkj,bnk->bj", Jc, wh)
+    g_bwd = hm.hand_pose.grad[:, 9:]
+    assert (g_explicit - g_bwd).norm() <= 1e-4 * g_bwd.norm()
+
+
+@pytest.mark.parametrize("hand_name,n", [("allegro", 4), ("allegro", 12), ("shadow_hand", 16), ("robotiq3", 12)])
+def test_required_joint_velocities(gq, hand_name, n):
+    """HandModel.get_req_joint_velocities: n = 4 on Allegro has 3n < n_dofs, where the reference's pinv takes its
+    right-inverse branch -- the same matrix as the left form the kernel solves."""
+    from graspqp_amd.core.hand_model import HandModel
+
+    spec = get_hand_spec(hand_name)
+    B = 6
+    hp = _pose(spec, B, 5)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(6))
+    md = 0.05 * torch.randn(B, n, 3, generator=torch.Generator().manual_seed(8), dtype=torch.float64)
+    oh = omodels.OracleHand(spec, torch.float64)
+    oh.set_parameters(hp, idx)
+    th_o, res_o, ee_o = oexp.get_req_joint_velocities(oh, md, idx, return_ee_vel=True)
+    hm = HandModel(spec, "cuda")
+    hm.set_parameters(hp.float().cuda(), idx.cuda())
+    th, res, ee = hm.get_req_joint_velocities(md.float().cuda(), idx.cuda(), return_ee_vel=True)
+    assert th.shape == (B, spec.n_dofs) and res.shape == (B, 3 * n) and ee.shape == (B, n, 3)
+    assert np.linalg.norm(th.cpu().numpy() - th_o.numpy()) <= 1e-3 * np.linalg.norm(th_o.numpy())
+    np.testing.assert_allclose(ee.cpu().numpy(), ee_o.numpy(), atol=2e-5)
+    np.testing.assert_allclose(res.cpu().numpy(), res_o.numpy(), atol=1e-6)
+    # all candidates (contact_point_indices=None) and the uncoupled form
+    th_all_o, _ = oexp.get_req_joint_velocities(oh, md[:, :1].expand(-1, spec.n_contact_candidates, -1).contiguous())
+    th_all, _ = hm.get_req_joint_velocities(md[:, :1].expand(-1, spec.n_contact_candidates, -1).float().cuda())
+    assert np.linalg.norm(th_all.cpu().numpy() - th_all_o.numpy()) <= 1e-3 * np.linalg.norm(th_all_o.numpy())
+    th_u_o, res_u_o = oexp.get_req_joint_velocities(oh, md, idx, coupled=False)
+    th_u, res_u = hm.get_req_joint_velocities(md.float().cuda(), idx.cuda(), coupled=False)
+    assert th_u.shape == (B, n, spec.n_dofs)
+    assert np.linalg.norm(th_u.cpu().numpy() - th_u_o.numpy()) <= 1e-3 * np.linalg.norm(th_u_o.numpy())
+
+
+def test_root_pose_quaternion(gq):
+    from scipy.spatial.transform import Rotation
+
+    g = torch.Generator().manual_seed(0)
+    hp = torch.randn(300, 25, generator=g, dtype=torch.float64)
+    hp[0, 3:9] = torch.tensor([1.0, 0, 0, 0, 1, 0])          # identity: trace branch
+    hp[1, 3:9] = torch.tensor([-1.0, 0, 0, 0, -1, 0])        # rotation by pi about z: R22 branch
+    hp[2, 3:9] = torch.tensor([1.0, 0, 0, 0, -1, 0])         # rotation by pi about x: R00 branch
+    out = gq.ops.root_pose_wxyz(hp.float().cuda()).cpu().numpy()
+    R = okin.special_gramschmidt(hp[:, 3:9])
+    q_o = oexp.rotmat_to_unitquat_xyzw(R)[:, [3, 0, 1, 2]].numpy()
+    np.testing.assert_allclose(out[:, :3], hp[:, :3].float().numpy(), rtol=0, atol=0)
+    # fp32 round-off can pick the other branch only where two branch keys tie, where both give the same rotation:
+    # compare as rotations first, then element-wise up to the common sign
+    q_s = Rotation.from_matrix(R.numpy()).as_quat()[:, [3, 0, 1, 2]]
+    dots = np.abs((out[:, 3:] * q_o).sum(-1))
+    assert (dots > 1 - 1e-6).all()
+    same_sign = np.abs(out[:, 3:] - q_o).max(-1) < 2e-6
+    assert same_sign.mean() > 0.98 and same_sign[:3].all()
+    np.testing.assert_allclose(q_o, q_s, atol=1e-12)
+
+
+def test_export_poses_file_layout_and_values(gq, tmp_path):
+    """export_poses writes what the reference's consumer reads (graspqp_isaaclab/.../utils/data.py:105-140), with the
+    oracle's values."""
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.export import export_poses
+
+    spec = get_hand_spec("allegro")
+    n_obj, be, n = 2, 3, 12
+    B = n_obj * be
+    fvs = [meshes.icosphere(2, 0.05), meshes.superquadric(5, 24, 12)]
+    sps = [meshes.surface_points(f, 300, oversample=4) for f in fvs]
+    hp = _pose(spec, B, 11)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=torch.Generator().manual_seed(2))
+    energy = torch.arange(B, dtype=torch.float32) * 1.5 - 2.0
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=300)
+    om.initialize_from_meshes(fvs, ["objA", "objB"], surface_points_list=sps)
+    hm.set_parameters(hp.float().cuda(), idx.cuda())
+    files = export_poses(hm, energy.cuda(), om, ["objA", "objB"], be, str(tmp_path), "allegro", n, "graspqp", suffix="_step_500")
+    assert [os.path.relpath(f, tmp_path) for f in files] == [
+        f"{c}/grasp_predictions/allegro/12_contacts/graspqp/default/{c}_step_500.dexgrasp.pt" for c in ("objA", "objB")]
+    assert torch.equal(hm.contact_point_indices.cpu(), idx), "export must leave the contact indices as they were"
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject(fvs, sps, be, torch.float64)
+    oh.set_parameters(hp, idx)
+    ref = oexp.export_poses(oh, oo, energy.double(), ["objA", "objB"], be)
+    names = list(spec.joint_names)
+    for a, f in enumerate(files):
+        data = torch.load(f, weights_only=True)
+        assert set(data) == {"values", "parameters", "grasp_velocities", "full_grasp_velocities", "grasp_velocities_off",
+                             "contact_idx", "grasp_type", "contact_links"}
+        assert data["grasp_type"] is None and data["contact_links"] is None
+        assert set(data["parameters"]) == set(names) | {"root_pose"}
+        assert data["parameters"]["root_pose"].shape == (be, 7) and data["contact_idx"].dtype == torch.int64
+        assert not data["values"].is_cuda and data["values"].dtype == torch.float32
+        np.testing.assert_allclose(data["values"].numpy(), ref[a]["values"].numpy(), rtol=1e-6)
+        np.testing.assert_allclose(data["parameters"]["root_pose"].numpy(), ref[a]["parameters"]["root_pose"].numpy(), atol=2e-6)
+        assert data["contact_idx"].tolist() == ref[a]["contact_idx"].tolist()
+        for key in ("grasp_velocities", "full_grasp_velocities", "grasp_velocities_off"):
+            got = torch.stack([data[key][nm] for nm in names], -1).numpy()
+            want = torch.stack([ref[a][key][nm] for nm in names], -1).numpy()
+            assert np.linalg.norm(got - want) <= 2e-3 * np.linalg.norm(want) + 1e-7, key
+        for i, nm in enumerate(names):
+            np.testing.assert_allclose(data["parameters"][nm].numpy(), hp[a * be : (a + 1) * be, 9 + i].float().numpy(), rtol=1e-6)
+        # the consumer's own assembly (data.py:105-140): parameters -> (B, 7 + J), velocities = off + 0.1 * grasp
+        values = torch.stack([data["parameters"][nm] for nm in names], dim=-1)
+        params = torch.cat([data["parameters"]["root_pose"], values], dim=-1)
+        vel = torch.stack([data["grasp_velocities_off"][nm] + 0.1 * data["grasp_velocities"][nm] for nm in names], dim=-1)
+        mask = data["values"] > -1e3
+        assert params[mask].shape == (be, 7 + len(names)) and vel.shape == (be, len(names)) and torch.isfinite(vel).all()

@@ -108,6 +108,16 @@ AcceptDesc = _struct("AcceptDesc", [
     ("annealing_period", "i"), ("energy", "p"), ("pose", "p"), ("idx", "p"), ("grad", "p"), ("accept", "p"),
     ("temperature", "p"), ("n_terms", "i"), ("terms_new", "p"), ("terms", "p"), ("slot_ctr", "p"), ("slots", "i")])
 
+InitDesc = _struct("InitDesc", [
+    ("hull_face_verts", "p"), ("hull_cdf", "p"), ("hull_offsets", "p"), ("n_obj", "l"), ("batch_each", "l"),
+    ("samples_per_object", "l"), ("n_dofs", "i"), ("inflate", "f"),
+    ("forward_axis0", "f"), ("forward_axis1", "f"), ("forward_axis2", "f"), ("up_axis0", "f"), ("up_axis1", "f"), ("up_axis2", "f"),
+    ("default_state", "p"), ("joints_lower", "p"), ("joints_upper", "p"),
+    ("jitter_strength", "f"), ("distance_lower", "f"), ("distance_upper", "f"), ("rotate_lower", "f"), ("rotate_upper", "f"),
+    ("pitch_lower", "f"), ("pitch_upper", "f"), ("tilt_lower", "f"), ("tilt_upper", "f"),
+    ("u_face", "p"), ("u_len", "p"), ("u_pose", "p"), ("u_joint", "p"), ("hand_pose", "p"), ("shell_points", "p"),
+    ("shell_dirs", "p"), ("workspace", "p"), ("workspace_bytes", "z")])
+
 _lib = None
 _protos = None
 

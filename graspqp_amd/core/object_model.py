@@ -33,6 +33,7 @@ class ObjectModel:
         self.surface_points_each = None  # (n_obj, P, 3), un-expanded
         self._meshset = None
         self._cog = None
+        self._hull = None  # (face_verts (sumF,3,3), area cdf (sumF), offsets (n_obj+1)) on the device, built on demand
         self.sdf_library = "HIP"
 
     @property
@@ -77,6 +78,23 @@ class ObjectModel:
             self.surface_points_each = sp.contiguous()
             self.surface_points_tensor = sp.repeat_interleave(self.batch_size_each, dim=0)
         self._cog = None
+        self._hull = None
+
+    def convex_hulls(self):
+        """Convex hull of every object (scaled like initializations.py:42-46) as device arrays for
+        ``initialize_convex_hull``: triangles oriented outward, per-object cumulative area table, offsets."""
+        if self._hull is None:
+            fvs, cdfs, off = [], [], [0]
+            for i, f in enumerate(self.object_mesh_list):
+                h = mesh_utils.convex_hull_faces(f.reshape(-1, 3) * float(self.object_scale_tensor[i].max().item()))
+                fvs.append(h)
+                cdfs.append(mesh_utils.area_cdf(h))
+                off.append(off[-1] + len(h))
+            self._hull = (torch.tensor(np.concatenate(fvs), dtype=torch.float32, device=self.device).contiguous(),
+                          torch.tensor(np.concatenate(cdfs), dtype=torch.float32, device=self.device).contiguous(),
+                          torch.tensor(off, dtype=torch.int32, device=self.device))
+            self.hull_face_verts_list = fvs
+        return self._hull
 
     def attach(self, hand_model):
         hand_model._batch_each_hint = self.batch_size_each

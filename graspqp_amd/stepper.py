@@ -363,26 +363,34 @@ class GraspStepper:
         self._slot_ctr += 1
         self._after_reset = False
 
-    def step_reset(self, reset_mask, new_pose, new_idx, draws=None):
+    def step_reset(self, reset_mask, new_pose, new_idx, draws=None, z_threshold=None):
         """One iteration of fit.py:399-458 in which the rows of ``reset_mask`` are re-initialised (fit.py:408-422): after
         the proposal their pose / contact indices are replaced by ``new_pose`` / ``new_idx`` (what the reference's
         initialize_convex_hull writes, full batch size; see ``graspqp_amd.core.initializations``), MalaStar.reset_envs zeroes their step
         counter, gradient EMA and old gradient and makes the new pose the "old" one, and the accept step accepts them
-        unconditionally.  Launched eagerly with the stand-alone propose / accept kernels (this happens every few hundred
-        iterations); the device-side draw-slot counter is advanced by hand so that graph replays stay in step."""
+        unconditionally.  ``reset_mask=None`` takes the reference's rule z_score > ``z_threshold`` (fit.py:409) from the
+        z-scores the proposal kernel has just computed -- on the device, without a host round trip.  Launched eagerly with
+        the stand-alone propose / accept kernels (this happens every few hundred iterations); the device-side draw-slot
+        counter is advanced by hand so that graph replays stay in step."""
         self.flush()
         self.draw(draws)
         st = _C.stream_ptr()
-        m = reset_mask.to(self.dev, torch.bool)
         self._propose(st)
+        if reset_mask is None:
+            m = self.z > float(z_threshold)  # NaN z (one-row objects) never resets, like the reference's comparison
+        else:
+            m = reset_mask.to(self.dev, torch.bool)
+        self.reset_mask = m
+        mc = m.unsqueeze(1)
         idx_all = new_idx.to(self.dev).contiguous()
-        self.pose_new[m] = new_pose.to(self.dev, torch.float32)[m]
-        self.idx_new[m] = idx_all[m]
-        self.step_count[m] = 0  # optimizer.py:275-284
-        self.ema[m] = 0
-        self.hand_pose[m] = self.pose_new[m]
-        self.contact_idx[m] = self.idx_new[m]
-        self.grad[m] = 0
+        # masked merges with torch.where: boolean-mask indexing would synchronise with the host
+        self.pose_new.copy_(torch.where(mc, new_pose.to(self.dev, torch.float32), self.pose_new))
+        self.idx_new.copy_(torch.where(mc, idx_all, self.idx_new))
+        self.step_count.masked_fill_(m, 0)  # optimizer.py:275-284
+        self.ema.masked_fill_(mc, 0.0)
+        self.hand_pose.copy_(torch.where(mc, self.pose_new, self.hand_pose))
+        self.contact_idx.copy_(torch.where(mc, self.idx_new, self.contact_idx))
+        self.grad.masked_fill_(mc, 0.0)
         # reference quirk (hand_model.py:815-831): set_parameters(..., env_mask) gathers the contact points of ALL rows with
         # the freshly drawn indices it is handed (initializations.py:190-193), while the rows outside the mask keep
         # their proposal's indices as state -- so this iteration's energies are evaluated at ``new_idx`` everywhere
@@ -404,6 +412,45 @@ class GraspStepper:
         self.flush()
         self._slot_ctr.zero_()
         self._draw_pos = 0
+
+    # ---- on-device (re-)initialisation: initialize_convex_hull, scripts/fit.py:315,408-422 ------------------------------
+    def set_hulls(self, hulls, init_args=None):
+        """``hulls`` = ObjectModel.convex_hulls() (device triangles, area table, offsets); ``init_args`` = the ranges of
+        scripts/fit.py:59-71 (Namespace / dict; reference defaults otherwise)."""
+        self._hulls, self._init_args = hulls, init_args
+
+    def fresh_state(self):
+        """hand_pose (B,D) and contact indices (B,n) of initialize_convex_hull for ALL rows, drawn with the stepper's
+        generator -- device tensors, nothing touches the host."""
+        from .core.initializations import convex_hull_poses
+
+        if getattr(self, "_hulls", None) is None:
+            raise RuntimeError("GraspStepper.set_hulls(object_model.convex_hulls()) must be called first")
+        pose = convex_hull_poses(self.hand.spec, self._hulls, self.n_obj, self.be, self._init_args, self.gen, self.dev)
+        idx = torch.randint(self.hand.spec.n_contact_candidates, (self.B, self.n), device=self.dev, generator=self.gen)
+        return pose, idx
+
+    def initialize(self):
+        """fit.py:315 + 381-396: initialize_convex_hull for every row, then the first energy evaluation."""
+        pose, idx = self.fresh_state()
+        self.reset(pose, idx)
+
+    def run(self, n_iter, reset_epochs=600, z_score_threshold=1.0, callback=None):
+        """The reference's schedule (fit.py:399-458): ``n_iter`` MALA* iterations; every ``reset_epochs`` iterations
+        (while step < n_iter - 2 * reset_epochs) the rows whose per-object z-score exceeds ``z_score_threshold`` are
+        re-initialised on the convex hull.  Ordinary iterations replay from the captured hipGraph, reset iterations are
+        launched eagerly; the host never waits for the device.  ``callback(step)`` (e.g. export_poses every 500
+        iterations, fit.py:518-521) is called after the iteration ``step``."""
+        for step in range(1, n_iter + 1):
+            if reset_epochs is not None and step % reset_epochs == 0 and step < n_iter - 2 * reset_epochs:
+                pose, idx = self.fresh_state()
+                self.step_reset(None, pose, idx, z_threshold=z_score_threshold)
+            else:
+                self.step()
+            if callback is not None:
+                self.flush()
+                callback(step)
+        self.flush()
 
     def flush(self):
         """Run the iterations that ``step`` has queued for a multi-iteration graph but not yet replayed."""

@@ -156,3 +156,26 @@ def surface_points(face_verts: np.ndarray, num_samples: int = 2500, oversample: 
     if sort:
         pts = pts[morton_order(pts)]
     return pts.astype(np.float32)
+
+
+def convex_hull_faces(verts: np.ndarray) -> np.ndarray:
+    """Outward-oriented triangles (F,3,3) float64 of the convex hull of ``verts`` (qhull through scipy; the reference
+    takes ``trimesh.Trimesh.convex_hull``, initializations.py:42).  Degenerate faces are dropped (:47)."""
+    from scipy.spatial import ConvexHull
+
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    hull = ConvexHull(v)
+    fv = v[hull.simplices]
+    n = np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0])
+    flip = (n * hull.equations[:, :3]).sum(1) < 0
+    fv[flip] = fv[flip][:, [0, 2, 1]]
+    area = 0.5 * np.linalg.norm(np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0]), axis=1)
+    return fv[area > 1e-14]
+
+
+def area_cdf(face_verts: np.ndarray) -> np.ndarray:
+    """Cumulative face area / total area (the table trimesh.sample.sample_surface searches)."""
+    fv = np.asarray(face_verts, dtype=np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0]), axis=1)
+    c = np.cumsum(area)
+    return c / c[-1]

@@ -294,6 +294,36 @@ int gq_axpy(float* y, const float* x, float a, int64_t n, void* stream);
 int gq_scale(float* y, const float* x, float a, int64_t n, void* stream);
 int gq_fill(float* y, float a, int64_t n, void* stream);
 
+/* ---- (re-)initialisation: initialize_convex_hull, core/initializations.py:15-193 (scripts/fit.py:315,408-422) --------
+ * Per object: samples_per_object points on its convex hull (area-weighted), pushed out by `inflate` (0.01 in the
+ * reference) along the face normal; farthest-point sampling of batch_each of them (start = sample 0); per row the look-at
+ * rotation towards the hull composed with a random roll / pitch / tilt, a random stand-off distance, and joint angles
+ * from a truncated normal around default_state (sigma = jitter_strength * joint range).  hand_pose (B, 9 + n_dofs),
+ * B = n_obj * batch_each, is written for ALL rows; applying it to the rows of an env_mask is the caller's business
+ * (HandModel.set_parameters(env_mask=...), GraspStepper.step_reset).  The hull (triangles oriented outward, set-up time)
+ * and every random number are inputs: u_face (n_obj, samples) and u_len (n_obj, samples, 2) pick the samples, u_pose
+ * (B,4) = distance / rotate / pitch / tilt and u_joint (B, n_dofs), all uniform in [0,1).  Contact indices are a plain
+ * randint (initializations.py:190-192) and stay with the caller.                                                    */
+typedef struct gqInitDesc {
+  const float* hull_face_verts;   /* (sumF,3,3) device */
+  const float* hull_cdf;          /* (sumF) device: cumulative face area / total area, per object */
+  const int32_t* hull_offsets;    /* (n_obj+1) device */
+  int64_t n_obj, batch_each, samples_per_object;
+  int32_t n_dofs;
+  float inflate;
+  float forward_axis[3], up_axis[3];                 /* HandModel.forward_axis / up_axis */
+  const float* default_state; const float* joints_lower; const float* joints_upper;  /* (n_dofs) device */
+  float jitter_strength, distance_lower, distance_upper, rotate_lower, rotate_upper, pitch_lower, pitch_upper,
+      tilt_lower, tilt_upper;                         /* scripts/fit.py:59-71 */
+  const float* u_face; const float* u_len; const float* u_pose; const float* u_joint;
+  float* hand_pose;               /* (B, 9 + n_dofs) out */
+  float* shell_points;            /* (B,3) out or NULL: the inflated hull point each row looks at */
+  float* shell_dirs;              /* (B,3) out or NULL: unit direction from that point towards the hull */
+  void* workspace; size_t workspace_bytes;           /* gq_init_workspace_bytes */
+} gqInitDesc;
+int gq_init_workspace_bytes(int64_t n_obj, int64_t samples_per_object, int64_t batch_each, size_t* bytes);
+int gq_init_convex_hull(const gqInitDesc* desc, void* stream);
+
 /* ---- MALA* optimiser: MalaStar.try_step / accept_step, core/optimizer.py:199-273,289-340; fit.py:403-406,454-458
  * random draws are inputs: u_switch (B,n) U[0,1), new_idx (B,n) in [0,C), u_accept (B) U[0,1).               */
 int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* contact_idx, const float* u_switch,

@@ -95,12 +95,14 @@ def test_descriptor_struct_layouts_match_the_header(tmp_path):
         pytest.skip("no C compiler")
     pairs = {"gqHandDesc": _C.HandDesc, "gqRowEnergyDesc": _C.RowEnergyDesc, "gqFcStepDesc": _C.FcStepDesc,
              "gqPenStepDesc": _C.PenStepDesc, "gqProposeDesc": _C.ProposeDesc, "gqAcceptDesc": _C.AcceptDesc,
-             "gqSdfDesc": _C.SdfDesc}
+             "gqSdfDesc": _C.SdfDesc, "gqInitDesc": _C.InitDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "graspqp_hip.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
         for fname, _ in cls._fields_:
-            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+            m = re.fullmatch(r"(\w+_axis)(\d)", fname)  # float[3] members are mirrored element by element
+            cfield = f"{m.group(1)}[{m.group(2)}]" if m else fname
+            lines.append(f'  printf(" %zu", offsetof({cname}, {cfield}));')
         lines.append('  printf("\\n");')
     lines += ["  return 0;", "}"]
     src = tmp_path / "layout.c"

@@ -207,3 +207,73 @@ def test_oracle_mala_clip_grad_with_nan_inf_matches_reference_optimizer(golden_d
     assert np.isnan(g["C_s1_grad_in"]).any() and np.isinf(g["C_s1_grad_in"]).any()
     assert np.isfinite(g["C_s1_prop_pose"]).all() and np.isfinite(g["C_s1_ema"]).all()
     _replay(g, "C", hand, obj, be, clip=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# (re-)initialisation: oracle/ref_cpu/init.py against the reference's initialize_convex_hull (fixture init_*.npz)
+# ---------------------------------------------------------------------------------------------------------------
+def test_oracle_initialization_matches_reference_initialize_convex_hull(golden_dir):
+    from ref_cpu import init as oinit
+
+    g = np.load(os.path.join(golden_dir, "init_allegro_sq_b12.npz"), allow_pickle=False)
+    spec = get_hand_spec("allegro")
+    n_obj, be = int(g["n_obj"]), int(g["batch_size_each"])
+    hulls = [g[f"obj{i}_hull_face_verts"] for i in range(n_obj)]
+    draws = {"u_face": torch.tensor(g["u_face"]), "u_len": torch.tensor(g["u_len"]), "u_pose": torch.tensor(g["u_pose"])}
+    pose, p, n = oinit.initialize_convex_hull(spec, hulls, be, draws, joints=torch.tensor(g["joints"]))
+    # the reference assembles in float32
+    np.testing.assert_allclose(pose.numpy(), g["hand_pose"], rtol=2e-5, atol=2e-6)
+    assert g["contact_idx"].tolist() == g["randint"].tolist()
+    # geometry of what the reference produced: the hand looks at the object from 5-10 cm outside the 1 cm shell
+    R = okin_gs(torch.tensor(g["hand_pose"][:, 3:9], dtype=torch.float64))
+    fwd_world = R @ torch.tensor(spec.forward_axis, dtype=torch.float64)
+    cos_tilt = (fwd_world * n).sum(-1)  # forward axis vs direction to the hull, tilted by at most 45 deg / 15 deg
+    assert (cos_tilt > np.cos(np.deg2rad(48))).all()
+    d = ((p - torch.tensor(g["hand_pose"][:, :3], dtype=torch.float64)) * n).sum(-1)
+    assert ((d > 0.05 - 1e-5) & (d < 0.1 + 1e-5)).all()
+    lo, hi = np.asarray(spec.joints_lower), np.asarray(spec.joints_upper)
+    assert ((g["joints"] >= lo - 2e-6) & (g["joints"] <= hi + 2e-6)).all()
+    # env_mask call (fit.py:421): rows outside the mask untouched
+    m = g["env_mask"]
+    assert np.array_equal(g["hand_pose_masked"][~m], g["hand_pose"][~m]) and not np.array_equal(g["hand_pose_masked"][m], g["hand_pose"][m])
+    assert np.array_equal(g["contact_idx_masked"][~m], g["contact_idx"][~m])
+
+
+def okin_gs(six):
+    from ref_cpu import kin
+
+    return kin.special_gramschmidt(six)
+
+
+def test_oracle_init_pieces_against_scipy_and_torch():
+    """The restated third-party pieces: euler2mat 'rxyz' == scipy's intrinsic XYZ; truncated normal == torch's
+    trunc_normal_ on the same uniform stream; farthest points / hull sanity."""
+    from scipy.spatial.transform import Rotation
+
+    from ref_cpu import init as oinit
+
+    g = torch.Generator().manual_seed(0)
+    ang = (torch.rand(40, 3, generator=g, dtype=torch.float64) - 0.5) * 6
+    np.testing.assert_allclose(oinit.euler2mat_rxyz(ang[:, 0], ang[:, 1], ang[:, 2]).numpy(),
+                               Rotation.from_euler("XYZ", ang.numpy()).as_matrix(), atol=1e-12)
+    for mean, std, a, b in ((0.2, 0.15, -0.3, 0.5), (1.0, 0.05, 0.9, 1.6), (0.0, 0.3, -0.1, 0.1)):
+        torch.manual_seed(3)
+        want = torch.nn.init.trunc_normal_(torch.empty(1000, dtype=torch.float64), mean, std, a, b)
+        torch.manual_seed(3)
+        # trunc_normal_ draws tensor.uniform_(2l-1, 2u-1) = from + U[0,1) * (to - from) on the same generator stream
+        u = torch.empty(1000, dtype=torch.float64).uniform_(0, 1)
+        t64 = lambda v: torch.tensor(v, dtype=torch.float64)
+        got = oinit.trunc_normal_from_uniform(u, t64(mean), t64(std), t64(a), t64(b))
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-9, atol=1e-12)
+    from graspqp_amd.utils import meshes
+
+    fv = meshes.superquadric(3, 24, 12)
+    hull = oinit.convex_hull_faces(fv.reshape(-1, 3))
+    nrm = oinit.face_normals(hull).numpy()
+    cen = hull.mean(1)
+    assert ((cen - hull.reshape(-1, 3).mean(0)) * nrm).sum(1).min() > 0, "hull faces must be oriented outward"
+    pts, f = oinit.sample_surface(hull, torch.rand(500, generator=g, dtype=torch.float64), torch.rand(500, 2, generator=g, dtype=torch.float64))
+    # samples lie on their faces
+    assert np.abs(((pts.numpy() - hull[f.numpy(), 0]) * nrm[f.numpy()]).sum(1)).max() < 1e-12
+    sel = oinit.farthest_points(pts, 20)
+    assert sel[0] == 0 and len(set(sel.tolist())) == 20

@@ -10,6 +10,8 @@ stores plain input/output tensors:
   energy_*.npz     reference core/energy.py::calculate_energy composed over the oracle models
   mala_*.npz       reference core/optimizer.py::MalaStar driven through the fit.py loop order for a
                    few iterations on the oracle models, with every torch.rand/randint draw recorded
+  init_*.npz       reference core/initializations.py::initialize_convex_hull with oracle stand-ins for trimesh /
+                   pytorch3d / transforms3d: look_at, pose assembly, truncated-normal joints, env_mask hand-over
   mala_ext_*.npz   the same with (R) the step counter started at 149 and a re-initialisation iteration
                    (reset_envs + accept_step(reset_mask)), (C) clip_grad=True and NaN / inf gradient entries
 
@@ -390,6 +392,128 @@ def gen_mala_ext(ref_energy, ref_opt):
     print("mala_ext: C accepts", [out[f"C_s{i}_accept"].tolist() for i in (1, 2)])
 
 
+def gen_init():
+    """reference core/initializations.py::initialize_convex_hull executed in place.  trimesh / pytorch3d / transforms3d
+    are not importable, so minimal stand-ins backed by the oracle's restatements (oracle/ref_cpu/init.py: hull sampling,
+    farthest points, closest point on the hull, euler2mat) are registered under those names -- they stay PARITY
+    UNPINNED; what the fixture pins is the reference's OWN arithmetic around them: look_at, distance / angle draws, the
+    translation / rotation assembly, the rot6d layout, truncated-normal joints, random contact indices and the
+    set_parameters(env_mask=...) hand-over (initializations.py:79-193)."""
+    from ref_cpu import init as oinit
+
+    tag, hand_name, n_obj, be, n = "allegro_sq_b12", "allegro", 2, 6, 4
+    rec = {"u_face": [], "u_len": [], "p": [], "nrm": [], "trunc": []}
+
+    class _Mesh:
+        def __init__(self, vertices=None, faces=None, fv=None):
+            if fv is None:
+                fv = np.asarray(vertices, dtype=np.float64)[np.asarray(faces)]
+            self.fv = np.asarray(fv, dtype=np.float64)
+            self.vertices = self.fv.reshape(-1, 3).copy()
+            self.faces = np.arange(len(self.vertices)).reshape(-1, 3)
+            self.face_normals = oinit.face_normals(self.fv).numpy()
+            self.nearest = self
+
+        def remove_degenerate_faces(self):
+            return np.ones(len(self.faces), dtype=bool)
+
+        @property
+        def convex_hull(self):
+            return _Mesh(fv=oinit.convex_hull_faces(self.vertices))
+
+        def on_surface(self, pts):  # trimesh.proximity: (closest, distance, triangle id)
+            from ref_cpu import sdf as osdf
+            _, _, _, cl = osdf.compute_sdf(torch.as_tensor(pts, dtype=torch.float64), torch.as_tensor(self.fv))
+            return cl.numpy(), None, None
+
+    def sample_surface_even(mesh, count):
+        u_face, u_len = torch.rand(count, dtype=torch.float64), torch.rand(count, 2, dtype=torch.float64)
+        pts, f = oinit.sample_surface(mesh.fv, u_face, u_len)
+        rec["u_face"].append(u_face), rec["u_len"].append(u_len)
+        return pts.numpy(), f.numpy()
+
+    def sample_farthest_points(points, K, random_start_point=False):
+        assert not random_start_point
+        idx = oinit.farthest_points(points[0], K)
+        return points[:, idx].float(), idx[None]  # float32 like the rest of the reference's pipeline
+
+    def euler2mat(ai, aj, ak, axes="sxyz"):
+        assert axes == "rxyz"
+        return oinit.euler2mat_rxyz(*(torch.as_tensor([float(v)], dtype=torch.float64) for v in (ai, aj, ak)))[0].numpy()
+
+    tm = types.ModuleType("trimesh")
+    tm.Trimesh = _Mesh
+    tm.sample = types.SimpleNamespace(sample_surface_even=sample_surface_even)
+    p3 = types.ModuleType("pytorch3d")
+    p3.ops = types.ModuleType("pytorch3d.ops")
+    p3.ops.sample_farthest_points = sample_farthest_points
+    p3.structures = types.ModuleType("pytorch3d.structures")
+    t3 = types.ModuleType("transforms3d")
+    t3.euler = types.SimpleNamespace(euler2mat=euler2mat)
+    saved = {k: sys.modules.get(k) for k in ("trimesh", "pytorch3d", "pytorch3d.ops", "pytorch3d.structures", "transforms3d")}
+    sys.modules.update({"trimesh": tm, "pytorch3d": p3, "pytorch3d.ops": p3.ops, "pytorch3d.structures": p3.structures,
+                        "transforms3d": t3})
+    try:
+        ref_init = load_ref("_ref_initializations", "core/initializations.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    spec = get_hand_spec(hand_name)
+    hand = omodels.OracleHand(spec, dtype=torch.float32)
+    hand.up_axis = torch.tensor(spec.up_axis, dtype=torch.float32)
+    hand.forward_axis = torch.tensor(spec.forward_axis, dtype=torch.float32)
+    fvs = [meshes.superquadric(31 + i, 24, 12) for i in range(n_obj)]
+    obj = types.SimpleNamespace(object_mesh_list=[_Mesh(fv=f) for f in fvs], batch_size_each=be, device="cpu",
+                                object_scale_tensor=torch.ones(n_obj, be), data_root_path="/data/synthetic")
+    args = types.SimpleNamespace(n_contact=n, **oinit.DEFAULT_ARGS)
+    torch.manual_seed(7)
+    # record torch.rand (distance / rotate / pitch / tilt, in that order per object), torch.randint (contact indices) and
+    # the truncated-normal joint columns
+    tn = torch.nn.init.trunc_normal_
+
+    def trunc(t, mean, std, a, b):
+        r = tn(t, float(mean), float(std), float(a), float(b))
+        rec["trunc"].append(r.clone())
+        return r
+
+    torch.nn.init.trunc_normal_ = trunc
+    try:
+        with _Recorder() as r0:
+            ref_init.initialize_convex_hull(hand, obj, args)
+    finally:
+        torch.nn.init.trunc_normal_ = tn
+    rands = [v for k, v in r0.log if k == "rand" and v.dim() == 1 and v.shape[0] == be]
+    assert len(rands) == 4 * n_obj
+    u_pose = torch.cat([torch.stack(rands[4 * i : 4 * i + 4], dim=1) for i in range(n_obj)])  # (B,4)
+    idx0 = [v for k, v in r0.log if k == "randint"][0]
+    pose0 = hand.hand_pose.detach().clone()
+    out = dict(n_obj=n_obj, batch_size_each=be, n_contact=n, hand_pose=pose0, contact_idx=hand.contact_point_indices.clone(),
+               randint=idx0, u_pose=u_pose, joints=torch.stack(rec["trunc"], dim=1),
+               u_face=torch.stack(rec["u_face"]), u_len=torch.stack(rec["u_len"]))
+    for i in range(n_obj):
+        out[f"obj{i}_face_verts"] = fvs[i]
+        out[f"obj{i}_hull_face_verts"] = obj.object_mesh_list[i].convex_hull.fv
+    # second call with an env_mask (fit.py:421): only the masked rows change
+    mask = torch.zeros(n_obj * be, dtype=torch.bool)
+    mask[[1, 4, 9]] = True
+    rec2 = {"u_face": [], "u_len": [], "trunc": []}
+    rec.update(rec2)
+    torch.nn.init.trunc_normal_ = trunc
+    try:
+        with _Recorder() as r1:
+            ref_init.initialize_convex_hull(hand, obj, args, env_mask=mask)
+    finally:
+        torch.nn.init.trunc_normal_ = tn
+    out.update(env_mask=mask, hand_pose_masked=hand.hand_pose.detach().clone(),
+               contact_idx_masked=hand.contact_point_indices.clone())
+    assert torch.equal(out["hand_pose_masked"][~mask], pose0[~mask]) and not torch.equal(out["hand_pose_masked"][mask], pose0[mask])
+    np.savez_compressed(os.path.join(OUT, f"init_{tag}.npz"), **to_np(out))
+    print("init: translation norms", pose0[:, :3].norm(dim=1).numpy().round(3).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     scipy_solver, registry = ref_metrics()
@@ -400,6 +524,7 @@ def main():
     gen_energy(ref_energy)
     gen_mala(ref_energy, ref_opt)
     gen_mala_ext(ref_energy, ref_opt)
+    gen_init()
 
 
 if __name__ == "__main__":

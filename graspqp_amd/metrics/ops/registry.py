@@ -15,6 +15,17 @@ from ..solver.qp_solver import SQPLsqSolver
 from .span import OverallFrictionConeSpanMetric
 
 
+def _require_hip_solver(solver_cls):
+    """The reference lets ``solver_cls`` choose the QP back end (span.py:23-37,299; registry.py:112).  Here the solve is
+    fused into the force-closure kernels, so the only class that can be honoured is the HIP ``SQPLsqSolver`` (or a
+    subclass); anything else is refused loudly instead of being silently replaced."""
+    if solver_cls is None or (isinstance(solver_cls, type) and issubclass(solver_cls, SQPLsqSolver)):
+        return
+    raise NotImplementedError(
+        f"solver_cls={getattr(solver_cls, '__name__', solver_cls)!r}: graspqp_amd runs the force-closure QP inside its HIP "
+        "kernels and honours only graspqp_amd.metrics.SQPLsqSolver here; for another solver use the reference's torch metric")
+
+
 class SpanMetricWrapper(torch.nn.Module):
     def __init__(self, metric=OverallFrictionConeSpanMetric, metric_kwargs: dict = {}):
         super().__init__()
@@ -32,7 +43,11 @@ class SpanMetricWrapper(torch.nn.Module):
             self._max_limit = self.metric_kwargs.pop("max_limit", None)
             self._friction = self.metric_kwargs.pop("friction", None)
             self._n_cone = self.metric_kwargs.pop("n_cone_vecs", 4)
-            self.metric_kwargs.pop("solver_cls", None)
+            _require_hip_solver(self.metric_kwargs.pop("solver_cls", None))
+            if self.metric is not OverallFrictionConeSpanMetric and not (
+                    isinstance(self.metric, type) and issubclass(self.metric, OverallFrictionConeSpanMetric)):
+                raise NotImplementedError(f"SpanMetricWrapper: metric {self.metric} is not the friction-cone span metric "
+                                          "the HIP kernels implement (metrics/ops/span.py:298)")
             self._initialized = True
         max_limit = 50.0 if self._max_limit is None else self._max_limit  # span.py:28 default
         e, xs = ops.fc_energy(

@@ -19,6 +19,10 @@ class OverallFrictionConeSpanMetric(torch.nn.Module):
         self._mu = friction if friction is not None else 0.2
         self.n_cone_vecs = n_cone_vecs
         self._max_limit_value = 50  # span.py:28 default; SpanMetricWrapper overrides it
+        if not (isinstance(solver_cls, type) and issubclass(solver_cls, SQPLsqSolver)):
+            raise NotImplementedError(
+                f"solver_cls={getattr(solver_cls, '__name__', solver_cls)!r}: the QP is solved inside the HIP force-closure "
+                "kernels; only graspqp_amd.metrics.SQPLsqSolver (or a subclass) can be honoured (reference span.py:23-37)")
         self._solver_cls = solver_cls
         self._cache = {}
 

@@ -1,18 +1,40 @@
 """Torch-facing wrappers of the HIP kernels (thin: allocate outputs, pass pointers, register autograd).
 
 Every function here runs on the current HIP stream through the C ABI (``graspqp_amd._C``); none has a CPU path.
-The autograd ``Function``s reproduce exactly the differentiability contract of the packages they replace:
-TorchSDF (only ``dist_sq`` w.r.t. ``points``), qpth (implicit KKT backward), pytorch_kinematics (full FK).
+The ops are registered with the dispatcher as ``torch.ops.graspqp_amd.*`` (``torch.library.custom_op`` for the CUDA/HIP
+device only, fake kernels for tracing, ``register_autograd`` for the backward -- itself a registered op), so they are
+visible to ``torch.compile`` / the profiler like any ATen op.  Their differentiability contracts are exactly those of
+the packages they replace: TorchSDF (only ``dist_sq`` w.r.t. ``points``), qpth (implicit KKT backward),
+pytorch_kinematics (full FK).  Opaque device objects (mesh sets, hands) cross the dispatcher as integer ids.
 """
 
-from __future__ import annotations
-
 import ctypes
+import weakref
+from typing import List, Tuple
 
 import numpy as np
 import torch
+from torch import Tensor
 
 from . import _C
+
+_custom_op = torch.library.custom_op
+_HANDLES = weakref.WeakValueDictionary()  # id -> MeshSet / HandHandle (ops take the id: only tensors and scalars may
+_next_id = [1]                            # cross the dispatcher)
+
+
+def _register_handle(obj) -> int:
+    i = _next_id[0]
+    _next_id[0] += 1
+    _HANDLES[i] = obj
+    return i
+
+
+def _handle(i: int):
+    try:
+        return _HANDLES[int(i)]
+    except KeyError:
+        raise RuntimeError(f"graspqp_amd: device object {i} no longer exists") from None
 
 # ----------------------------------------------------------------------------------------------------------
 # helpers
@@ -58,6 +80,7 @@ class MeshSet:
             ctypes.byref(h),
         )
         self.handle = h
+        self.hid = _register_handle(self)
 
     def __del__(self):
         try:
@@ -76,73 +99,97 @@ def index_vertices_by_faces(verts: torch.Tensor, faces: torch.Tensor) -> torch.T
     return verts[faces.long()]
 
 
-class _ComputeSDF(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, points, face_verts):
-        pts = _c(points.detach())
-        fv = _c(face_verts.detach())
-        if pts.dim() != 2 or pts.shape[1] != 3:
-            raise ValueError(f"compute_sdf: points must be (N,3), got {tuple(pts.shape)}")
-        if fv.dim() != 3 or fv.shape[1:] != (3, 3):
-            raise ValueError(f"compute_sdf: face_verts must be (F,3,3), got {tuple(fv.shape)}")
-        N, F = pts.shape[0], fv.shape[0]
-        dev = pts.device
-        d2 = torch.empty(N, device=dev)
-        sgn = torch.empty(N, dtype=torch.int32, device=dev)
-        nrm = torch.empty(N, 3, device=dev)
-        cls = torch.empty(N, 3, device=dev)
-        if N > 0:
-            nb = _size_call("gq_sdf_workspace_bytes", ctypes.c_int64(F))
-            ws = _ws(nb, dev)
-            _C.call("gq_sdf_forward", _C.f32(pts), N, _C.f32(fv), F, _C.f32(d2), _C.i32(sgn), _C.f32(nrm), _C.f32(cls),
-                    _C.ptr(ws), nb, _C.stream_ptr())
-        ctx.save_for_backward(pts, cls)
-        ctx.mark_non_differentiable(sgn, nrm, cls)
-        return d2, sgn, nrm, cls
+@_custom_op("graspqp_amd::sdf_backward", mutates_args=(), device_types="cuda")
+def _sdf_backward(g_d2: Tensor, points: Tensor, closest: Tensor) -> Tensor:
+    gp = torch.empty_like(points)
+    if points.shape[0] > 0:
+        _C.call("gq_sdf_backward", _C.f32(_c(g_d2)), _C.f32(points), _C.f32(closest), points.shape[0], _C.f32(gp),
+                _C.stream_ptr())
+    return gp
 
-    @staticmethod
-    def backward(ctx, g_d2, g_sgn, g_nrm, g_cls):
-        pts, cls = ctx.saved_tensors
-        N = pts.shape[0]
-        gp = torch.empty_like(pts)
-        if N > 0:
-            _C.call("gq_sdf_backward", _C.f32(_c(g_d2)), _C.f32(pts), _C.f32(cls), N, _C.f32(gp), _C.stream_ptr())
-        return gp, None
+
+@_sdf_backward.register_fake
+def _(g_d2, points, closest):
+    return torch.empty_like(points)
+
+
+def _sdf_outputs(pts):
+    N, dev = pts.shape[0], pts.device
+    return (torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 3, device=dev),
+            torch.empty(N, 3, device=dev))
+
+
+@_custom_op("graspqp_amd::compute_sdf", mutates_args=(), device_types="cuda")
+def _compute_sdf_op(points: Tensor, face_verts: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    pts, fv = _c(points), _c(face_verts)
+    d2, sgn, nrm, cls = _sdf_outputs(pts)
+    N, F = pts.shape[0], fv.shape[0]
+    if N > 0:
+        nb = _size_call("gq_sdf_workspace_bytes", ctypes.c_int64(F))
+        ws = _ws(nb, pts.device)
+        _C.call("gq_sdf_forward", _C.f32(pts), N, _C.f32(fv), F, _C.f32(d2), _C.i32(sgn), _C.f32(nrm), _C.f32(cls),
+                _C.ptr(ws), nb, _C.stream_ptr())
+    return d2, sgn, nrm, cls
+
+
+@_compute_sdf_op.register_fake
+def _(points, face_verts):
+    return _sdf_outputs(points)
+
+
+def _sdf_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]), output[3])
+
+
+def _sdf_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
+    pts, cls = ctx.saved_tensors
+    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls), None
+
+
+torch.library.register_autograd("graspqp_amd::compute_sdf", _sdf_bwd, setup_context=_sdf_setup)
 
 
 def compute_sdf(points: torch.Tensor, face_verts: torch.Tensor):
     """torchsdf.compute_sdf drop-in -> (dist_sq, sign int32, normal, closest)."""
-    return _ComputeSDF.apply(points, face_verts)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError(f"compute_sdf: points must be (N,3), got {tuple(points.shape)}")
+    if face_verts.dim() != 3 or tuple(face_verts.shape[1:]) != (3, 3):
+        raise ValueError(f"compute_sdf: face_verts must be (F,3,3), got {tuple(face_verts.shape)}")
+    if not points.is_cuda:
+        raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
+    return torch.ops.graspqp_amd.compute_sdf(points, face_verts)
 
 
-class _SdfMeshSet(torch.autograd.Function):
+@_custom_op("graspqp_amd::sdf_meshset", mutates_args=(), device_types="cuda")
+def _sdf_meshset_op(points: Tensor, meshset: int, queries_per_mesh: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """compute_sdf of n_mesh groups of queries against a MeshSet (object_model.py:217-220 without the loop)."""
+    pts = _c(points).reshape(-1, 3)
+    d2, sgn, nrm, cls = _sdf_outputs(pts)
+    _C.call("gq_sdf_forward_meshset", _handle(meshset).handle, _C.f32(pts), pts.shape[0], int(queries_per_mesh), _C.f32(d2),
+            _C.i32(sgn), _C.f32(nrm), _C.f32(cls), _C.stream_ptr())
+    return d2, sgn, nrm, cls
 
-    @staticmethod
-    def forward(ctx, points, meshset, queries_per_mesh):
-        pts = _c(points.detach()).reshape(-1, 3)
-        N = pts.shape[0]
-        dev = pts.device
-        d2 = torch.empty(N, device=dev)
-        sgn = torch.empty(N, dtype=torch.int32, device=dev)
-        nrm = torch.empty(N, 3, device=dev)
-        cls = torch.empty(N, 3, device=dev)
-        _C.call("gq_sdf_forward_meshset", meshset.handle, _C.f32(pts), N, int(queries_per_mesh), _C.f32(d2), _C.i32(sgn),
-                _C.f32(nrm), _C.f32(cls), _C.stream_ptr())
-        ctx.save_for_backward(pts, cls)
-        ctx.mark_non_differentiable(sgn, nrm, cls)
-        return d2, sgn, nrm, cls
 
-    @staticmethod
-    def backward(ctx, g_d2, g_sgn, g_nrm, g_cls):
-        pts, cls = ctx.saved_tensors
-        gp = torch.empty_like(pts)
-        _C.call("gq_sdf_backward", _C.f32(_c(g_d2)), _C.f32(pts), _C.f32(cls), pts.shape[0], _C.f32(gp), _C.stream_ptr())
-        return gp, None, None
+@_sdf_meshset_op.register_fake
+def _(points, meshset, queries_per_mesh):
+    return _sdf_outputs(points.reshape(-1, 3))
+
+
+def _sdf_ms_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]).reshape(-1, 3), output[3])
+    ctx.in_shape = inputs[0].shape
+
+
+def _sdf_ms_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
+    pts, cls = ctx.saved_tensors
+    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None, None
+
+
+torch.library.register_autograd("graspqp_amd::sdf_meshset", _sdf_ms_bwd, setup_context=_sdf_ms_setup)
 
 
 def sdf_meshset(points, meshset: MeshSet, queries_per_mesh: int):
-    return _SdfMeshSet.apply(points, meshset, queries_per_mesh)
+    return torch.ops.graspqp_amd.sdf_meshset(points, meshset.hid, int(queries_per_mesh))
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -153,134 +200,204 @@ def _qp_ws(B, nz, max_iter, dev):
     return _ws(nb, dev), nb
 
 
-class _BoxQP(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, Q, p, lower, upper, eps, max_iter, not_improved_lim):
-        Qc, pc, lc, uc = _c(Q.detach()), _c(p.detach()), _c(lower.detach()), _c(upper.detach())
-        B, nz = pc.shape
-        dev = Qc.device
-        x = torch.empty(B, nz, device=dev)
-        lam = torch.empty(B, 2 * nz, device=dev)
-        slack = torch.empty(B, 2 * nz, device=dev)
-        nit = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws, nb = _qp_ws(B, nz, max_iter, dev)
-        _C.call("gq_boxqp_forward", _C.f32(Qc), _C.f32(pc), _C.f32(lc), _C.f32(uc), 0.0, 0.0, B, nz, float(eps),
-                int(max_iter), int(not_improved_lim), _C.f32(x), _C.f32(lam), _C.f32(slack), None, _C.i32(nit),
-                _C.ptr(ws), nb, _C.stream_ptr())
-        ctx.save_for_backward(Qc, x, lam, slack)
-        ctx.n_iter = nit
-        ctx.mark_non_differentiable(lam, slack)
-        return x, lam, slack
+@_custom_op("graspqp_amd::box_qp", mutates_args=(), device_types="cuda")
+def _box_qp_op(Q: Tensor, p: Tensor, lower: Tensor, upper: Tensor, eps: float, max_iter: int,
+               not_improved_lim: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    Qc, pc, lc, uc = _c(Q), _c(p), _c(lower), _c(upper)
+    B, nz = pc.shape
+    dev = Qc.device
+    x = torch.empty(B, nz, device=dev)
+    lam = torch.empty(B, 2 * nz, device=dev)
+    slack = torch.empty(B, 2 * nz, device=dev)
+    nit = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws, nb = _qp_ws(B, nz, max_iter, dev)
+    _C.call("gq_boxqp_forward", _C.f32(Qc), _C.f32(pc), _C.f32(lc), _C.f32(uc), 0.0, 0.0, B, nz, float(eps),
+            int(max_iter), int(not_improved_lim), _C.f32(x), _C.f32(lam), _C.f32(slack), None, _C.i32(nit),
+            _C.ptr(ws), nb, _C.stream_ptr())
+    return x, lam, slack, nit
 
-    @staticmethod
-    def backward(ctx, gx, g_lam, g_slack):
-        Qc, x, lam, slack = ctx.saved_tensors
-        B, nz = x.shape
-        dx = torch.empty_like(x)
-        dlam = torch.empty_like(lam)
-        _C.call("gq_boxqp_backward", _C.f32(Qc), _C.f32(lam), _C.f32(slack), _C.f32(_c(gx)), B, nz, _C.f32(dx),
-                _C.f32(dlam), _C.stream_ptr())
-        gQ = 0.5 * (dx.unsqueeze(2) * x.unsqueeze(1) + x.unsqueeze(2) * dx.unsqueeze(1))
-        # h = [upper; -lower]; grad_h = -dlam
-        g_upper = -dlam[:, :nz]
-        g_lower = dlam[:, nz:]
-        return gQ, dx, g_lower, g_upper, None, None, None
+
+@_box_qp_op.register_fake
+def _(Q, p, lower, upper, eps, max_iter, not_improved_lim):
+    B, nz = p.shape
+    return (p.new_empty(B, nz), p.new_empty(B, 2 * nz), p.new_empty(B, 2 * nz), p.new_empty(1, dtype=torch.int32))
+
+
+@_custom_op("graspqp_amd::box_qp_backward", mutates_args=(), device_types="cuda")
+def _box_qp_bwd_op(Q: Tensor, lam: Tensor, slack: Tensor, gx: Tensor) -> Tuple[Tensor, Tensor]:
+    B, nz = gx.shape
+    dx = torch.empty(B, nz, device=gx.device)
+    dlam = torch.empty(B, 2 * nz, device=gx.device)
+    _C.call("gq_boxqp_backward", _C.f32(_c(Q)), _C.f32(lam), _C.f32(slack), _C.f32(_c(gx)), B, nz, _C.f32(dx), _C.f32(dlam),
+            _C.stream_ptr())
+    return dx, dlam
+
+
+@_box_qp_bwd_op.register_fake
+def _(Q, lam, slack, gx):
+    return torch.empty_like(gx), torch.empty_like(lam)
+
+
+def _box_qp_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]), output[0], output[1], output[2])
+
+
+def _box_qp_bwd(ctx, gx, g_lam, g_slack, g_nit):
+    Qc, x, lam, slack = ctx.saved_tensors
+    nz = x.shape[1]
+    dx, dlam = torch.ops.graspqp_amd.box_qp_backward(Qc, lam, slack, gx)
+    gQ = 0.5 * (dx.unsqueeze(2) * x.unsqueeze(1) + x.unsqueeze(2) * dx.unsqueeze(1))
+    # h = [upper; -lower]; grad_h = -dlam
+    return gQ, dx, dlam[:, nz:], -dlam[:, :nz], None, None, None
+
+
+torch.library.register_autograd("graspqp_amd::box_qp", _box_qp_bwd, setup_context=_box_qp_setup)
 
 
 def box_qp(Q, p, lower, upper, eps=5e-2, max_iter=12, not_improved_lim=3):
     """argmin 1/2 x'Qx + p'x, lower <= x <= upper -> (x, lam, slack); differentiable (qpth semantics)."""
-    return _BoxQP.apply(Q, p, lower, upper, eps, max_iter, not_improved_lim)
+    x, lam, slack, _ = torch.ops.graspqp_amd.box_qp(Q, p, lower, upper, float(eps), int(max_iter), int(not_improved_lim))
+    return x, lam, slack
 
 
-class _LsqBoxQP(torch.autograd.Function):
-    """x = argmin 1/2 x'(A'A + ridge I)x - (A'b)'x in the box; backward to A and b (qp_solver.py:101-126)."""
-
-    @staticmethod
-    def forward(ctx, A, b, lower_s, upper_s, ridge, eps, max_iter):
-        Ac = _c(A.detach())
-        bc = None if b is None else _c(b.detach())
-        B, m, nz = Ac.shape
-        dev = Ac.device
-        x = torch.empty(B, nz, device=dev)
-        lam = torch.empty(B, 2 * nz, device=dev)
-        slack = torch.empty(B, 2 * nz, device=dev)
-        nit = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws, nb = _qp_ws(B, nz, max_iter, dev)
-        _C.call("gq_lsq_boxqp_forward", _C.f32(Ac), _C.f32(bc), None, None, float(lower_s), float(upper_s), B, m, nz,
-                float(ridge), float(eps), int(max_iter), 3, _C.f32(x), _C.f32(lam), _C.f32(slack), None, _C.i32(nit),
-                _C.ptr(ws), nb, _C.stream_ptr())
-        ctx.save_for_backward(Ac, bc if bc is not None else torch.zeros(B, m, device=dev), x, lam, slack)
-        ctx.ridge = ridge
-        ctx.has_b = b is not None
-        ctx.n_iter = nit
-        return x
-
-    @staticmethod
-    def backward(ctx, gx):
-        Ac, bc, x, lam, slack = ctx.saved_tensors
-        B, m, nz = Ac.shape
-        dx = torch.empty_like(x)
-        dlam = torch.empty_like(lam)
-        _C.call("gq_lsq_boxqp_backward", _C.f32(Ac), _C.f32(lam), _C.f32(slack), _C.f32(_c(gx)), B, m, nz,
-                float(ctx.ridge), _C.f32(dx), _C.f32(dlam), _C.stream_ptr())
-        # Q = A'A + ridge I -> grad_A = A (dx x' + x dx');  p = -A'b -> grad_A += -b dx', grad_b = -A dx
-        Adx = (Ac @ dx.unsqueeze(-1)).squeeze(-1)
-        Ax = (Ac @ x.unsqueeze(-1)).squeeze(-1)
-        gA = Adx.unsqueeze(2) * x.unsqueeze(1) + Ax.unsqueeze(2) * dx.unsqueeze(1) - bc.unsqueeze(2) * dx.unsqueeze(1)
-        gb = -Adx if ctx.has_b else None
-        return gA, gb, None, None, None, None, None
+@_custom_op("graspqp_amd::lsq_box_qp", mutates_args=(), device_types="cuda")
+def _lsq_box_qp_op(A: Tensor, b: Tensor, lower_s: float, upper_s: float, ridge: float, eps: float,
+                   max_iter: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """x = argmin 1/2 x'(A'A + ridge I)x - (A'b)'x in the box (qp_solver.py:101-126) -> (x, lam, slack, n_iter)."""
+    Ac, bc = _c(A), _c(b)
+    B, m, nz = Ac.shape
+    dev = Ac.device
+    x = torch.empty(B, nz, device=dev)
+    lam = torch.empty(B, 2 * nz, device=dev)
+    slack = torch.empty(B, 2 * nz, device=dev)
+    nit = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws, nb = _qp_ws(B, nz, max_iter, dev)
+    _C.call("gq_lsq_boxqp_forward", _C.f32(Ac), _C.f32(bc), None, None, float(lower_s), float(upper_s), B, m, nz,
+            float(ridge), float(eps), int(max_iter), 3, _C.f32(x), _C.f32(lam), _C.f32(slack), None, _C.i32(nit),
+            _C.ptr(ws), nb, _C.stream_ptr())
+    return x, lam, slack, nit
 
 
-def lsq_box_qp(A, b, lower, upper, ridge=1e-4, eps=5e-2, max_iter=12):
-    return _LsqBoxQP.apply(A, b, lower, upper, ridge, eps, max_iter)
+@_lsq_box_qp_op.register_fake
+def _(A, b, lower_s, upper_s, ridge, eps, max_iter):
+    B, m, nz = A.shape
+    return (A.new_empty(B, nz), A.new_empty(B, 2 * nz), A.new_empty(B, 2 * nz), A.new_empty(1, dtype=torch.int32))
+
+
+@_custom_op("graspqp_amd::lsq_box_qp_backward", mutates_args=(), device_types="cuda")
+def _lsq_box_qp_bwd_op(A: Tensor, lam: Tensor, slack: Tensor, gx: Tensor, ridge: float) -> Tuple[Tensor, Tensor]:
+    B, m, nz = A.shape
+    dx = torch.empty(B, nz, device=A.device)
+    dlam = torch.empty(B, 2 * nz, device=A.device)
+    _C.call("gq_lsq_boxqp_backward", _C.f32(_c(A)), _C.f32(lam), _C.f32(slack), _C.f32(_c(gx)), B, m, nz, float(ridge),
+            _C.f32(dx), _C.f32(dlam), _C.stream_ptr())
+    return dx, dlam
+
+
+@_lsq_box_qp_bwd_op.register_fake
+def _(A, lam, slack, gx, ridge):
+    return torch.empty_like(gx), torch.empty_like(lam)
+
+
+def _lsq_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]), _c(inputs[1]), output[0], output[1], output[2])
+    ctx.ridge = inputs[4]
+
+
+def _lsq_bwd(ctx, gx, g_lam, g_slack, g_nit):
+    Ac, bc, x, lam, slack = ctx.saved_tensors
+    dx, _ = torch.ops.graspqp_amd.lsq_box_qp_backward(Ac, lam, slack, gx, ctx.ridge)
+    # Q = A'A + ridge I -> grad_A = A (dx x' + x dx');  p = -A'b -> grad_A += -b dx', grad_b = -A dx
+    Adx = (Ac @ dx.unsqueeze(-1)).squeeze(-1)
+    Ax = (Ac @ x.unsqueeze(-1)).squeeze(-1)
+    gA = Adx.unsqueeze(2) * x.unsqueeze(1) + Ax.unsqueeze(2) * dx.unsqueeze(1) - bc.unsqueeze(2) * dx.unsqueeze(1)
+    return gA, -Adx, None, None, None, None, None
+
+
+torch.library.register_autograd("graspqp_amd::lsq_box_qp", _lsq_bwd, setup_context=_lsq_setup)
+
+
+def lsq_box_qp(A, b, lower, upper, ridge=1e-4, eps=5e-2, max_iter=12, return_n_iter=False):
+    """x (B,nz); with ``return_n_iter`` also the (1,) int32 iteration count of qpth's batch-global stop rule."""
+    if b is None:
+        b = torch.zeros(A.shape[0], A.shape[1], device=A.device, dtype=A.dtype)
+    x, _, _, nit = torch.ops.graspqp_amd.lsq_box_qp(A, b, float(lower), float(upper), float(ridge), float(eps), int(max_iter))
+    return (x, nit) if return_n_iter else x
 
 
 # ----------------------------------------------------------------------------------------------------------
 # fused force-closure energy
 # ----------------------------------------------------------------------------------------------------------
-class _FcEnergy(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, contact_pts, contact_normals, cog, cfg):
-        cp, cn, cg = _c(contact_pts.detach()), _c(contact_normals.detach()), _c(cog.detach())
-        B, n, _ = cp.shape
-        k = int(cfg["n_cone_vecs"])
-        dev = cp.device
-        e = torch.empty(B, device=dev)
-        xs = torch.empty(B, n, device=dev)
-        nit = torch.zeros(1, dtype=torch.int32, device=dev)
-        nb = _size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, k, int(cfg["max_iter"]))
-        ws = _ws(nb, dev)
-        _C.call("gq_fc_forward", _C.f32(cp), _C.f32(cn), _C.f32(cg), B, n, k, float(cfg["friction"]),
-                float(cfg["torque_weight"]), float(cfg["max_limit"]), float(cfg["svd_gain"]), float(cfg["values_gain"]),
-                float(cfg["eps"]), int(cfg["max_iter"]), _C.f32(e), _C.f32(xs), _C.i32(nit), _C.ptr(ws), nb,
-                _C.stream_ptr())
-        ctx.save_for_backward(cp, cn, cg, ws)
-        ctx.cfg = dict(cfg)
-        ctx.nb = nb
-        ctx.mark_non_differentiable(xs)
-        return e, xs
+@_custom_op("graspqp_amd::fc_energy", mutates_args=(), device_types="cuda")
+def _fc_energy_op(contact_pts: Tensor, contact_normals: Tensor, cog: Tensor, n_cone_vecs: int, friction: float,
+                  torque_weight: float, max_limit: float, svd_gain: float, values_gain: float, eps: float,
+                  max_iter: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """-> (E_fc (B), force sums (B,n), n_iter (1) int32, workspace kept for the backward)."""
+    cp, cn, cg = _c(contact_pts), _c(contact_normals), _c(cog)
+    B, n, _ = cp.shape
+    dev = cp.device
+    e = torch.empty(B, device=dev)
+    xs = torch.empty(B, n, device=dev)
+    nit = torch.zeros(1, dtype=torch.int32, device=dev)
+    nb = _size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, int(n_cone_vecs), int(max_iter))
+    ws = _ws(nb, dev)
+    _C.call("gq_fc_forward", _C.f32(cp), _C.f32(cn), _C.f32(cg), B, n, int(n_cone_vecs), float(friction),
+            float(torque_weight), float(max_limit), float(svd_gain), float(values_gain), float(eps), int(max_iter),
+            _C.f32(e), _C.f32(xs), _C.i32(nit), _C.ptr(ws), nb, _C.stream_ptr())
+    return e, xs, nit, ws
 
-    @staticmethod
-    def backward(ctx, ge, g_xs):
-        cp, cn, cg, ws = ctx.saved_tensors
-        cfg = ctx.cfg
-        B, n, _ = cp.shape
-        gp = torch.empty_like(cp)
-        _C.call("gq_fc_backward", _C.f32(cp), _C.f32(cn), _C.f32(cg), _C.f32(_c(ge)), B, n, int(cfg["n_cone_vecs"]),
-                float(cfg["friction"]), float(cfg["torque_weight"]), float(cfg["svd_gain"]), float(cfg["values_gain"]), 0,
-                _C.f32(gp), _C.ptr(ws), ctx.nb, _C.stream_ptr())
-        return gp, None, None, None
+
+@_fc_energy_op.register_fake
+def _(contact_pts, contact_normals, cog, n_cone_vecs, friction, torque_weight, max_limit, svd_gain, values_gain, eps, max_iter):
+    B, n, _ = contact_pts.shape
+    return (contact_pts.new_empty(B), contact_pts.new_empty(B, n), contact_pts.new_empty(1, dtype=torch.int32),
+            contact_pts.new_empty(1, dtype=torch.uint8))
+
+
+@_custom_op("graspqp_amd::fc_energy_backward", mutates_args=("ws",), device_types="cuda")  # scratch inside the workspace
+def _fc_energy_bwd_op(contact_pts: Tensor, contact_normals: Tensor, cog: Tensor, ge: Tensor, ws: Tensor, n_cone_vecs: int,
+                      friction: float, torque_weight: float, svd_gain: float, values_gain: float) -> Tensor:
+    gp = torch.empty_like(contact_pts)
+    B, n, _ = contact_pts.shape
+    _C.call("gq_fc_backward", _C.f32(contact_pts), _C.f32(contact_normals), _C.f32(cog), _C.f32(_c(ge)), B, n,
+            int(n_cone_vecs), float(friction), float(torque_weight), float(svd_gain), float(values_gain), 0, _C.f32(gp),
+            _C.ptr(ws), ws.numel(), _C.stream_ptr())
+    return gp
+
+
+@_fc_energy_bwd_op.register_fake
+def _(contact_pts, contact_normals, cog, ge, ws, n_cone_vecs, friction, torque_weight, svd_gain, values_gain):
+    return torch.empty_like(contact_pts)
+
+
+def _fc_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]), _c(inputs[1]), _c(inputs[2]), output[3])
+    ctx.cfg = inputs[3:]
+
+
+def _fc_bwd(ctx, ge, g_xs, g_nit, g_ws):
+    cp, cn, cg, ws = ctx.saved_tensors
+    k, mu, tw, _ml, sg, vg, _eps, _mi = ctx.cfg
+    gp = torch.ops.graspqp_amd.fc_energy_backward(cp, cn, cg, ge, ws, k, mu, tw, sg, vg)
+    return (gp,) + (None,) * 10
+
+
+torch.library.register_autograd("graspqp_amd::fc_energy", _fc_bwd, setup_context=_fc_setup)
 
 
 FC_DEFAULTS = dict(friction=0.2, n_cone_vecs=4, torque_weight=5.0, max_limit=20.0, svd_gain=0.1, values_gain=2.0,
                    eps=5e-2, max_iter=12)
 
 
-def fc_energy(contact_pts, contact_normals, cog, **cfg):
+def fc_energy(contact_pts, contact_normals, cog, return_n_iter=False, **cfg):
     """E_fc (B,) and per-contact force sums (B,n); gradient flows to contact_pts only (normals are SDF constants)."""
     c = dict(FC_DEFAULTS)
     c.update(cfg)
-    return _FcEnergy.apply(contact_pts, contact_normals, cog, c)
+    e, xs, nit, _ = torch.ops.graspqp_amd.fc_energy(
+        contact_pts, contact_normals.detach(), cog.detach(), int(c["n_cone_vecs"]), float(c["friction"]),
+        float(c["torque_weight"]), float(c["max_limit"]), float(c["svd_gain"]), float(c["values_gain"]), float(c["eps"]),
+        int(c["max_iter"]))
+    return (e, xs, nit) if return_n_iter else (e, xs)
 
 
 def fc_peek(ws, B, n, k):
@@ -328,6 +445,7 @@ class HandHandle:
         self.links = MeshSet([spec.link_faces(l) for l in range(spec.n_links)])
         _C.call("gq_meshset_build_occupancy", self.links.handle)
         self.J, self.L, self.S = spec.n_dofs, spec.n_links, spec.n_spheres
+        self.hid = _register_handle(self)
 
     def fk_ws(self, B, dev):
         nb = _size_call("gq_fk_workspace_bytes", self.handle, ctypes.c_int64(B))
@@ -342,53 +460,82 @@ class HandHandle:
             pass
 
 
-class _FK(torch.autograd.Function):
-    """hand_pose, contact idx -> (Rg (B,3,3), link_T (B,L,3,4), contact_points, contact_normals, sphere_centers)."""
-
-    @staticmethod
-    def forward(ctx, hand_pose, idx, hand):
-        hp = _c(hand_pose.detach())
-        ix = _c(idx, torch.int64)
-        B, n = ix.shape
-        dev = hp.device
-        Rg = torch.empty(B, 3, 3, device=dev)
-        LT = torch.empty(B, hand.L, 3, 4, device=dev)
-        cp = torch.empty(B, n, 3, device=dev)
-        cn = torch.empty(B, n, 3, device=dev)
-        sc = torch.empty(B, max(hand.S, 1), 3, device=dev)
-        ws, nb = hand.fk_ws(B, dev)
-        _C.call("gq_fk_forward", hand.handle, _C.f32(hp), _C.i64(ix), B, n, _C.f32(Rg), _C.f32(LT), _C.f32(cp),
-                _C.f32(cn), _C.f32(sc) if hand.S > 0 else None, 0.0, None, None, None, None, _C.ptr(ws), nb, _C.stream_ptr())
-        ctx.save_for_backward(hp, ix, Rg, LT, ws)
-        ctx.hand = hand
-        ctx.nb = nb
-        ctx.mark_non_differentiable(ws)
-        return Rg, LT, cp, cn, sc[:, : hand.S], ws
-
-    @staticmethod
-    def backward(ctx, gRg, gLT, gcp, gcn, gsc, gws):
-        hp, ix, Rg, LT, ws = ctx.saved_tensors
-        hand = ctx.hand
-        B, n = ix.shape
-        if gLT is not None and bool((gLT != 0).any()):
-            raise RuntimeError("gradient w.r.t. link transforms must come through hand_pen (link wrench), not link_T")
-        return _fk_backward(hand, hp, ix, Rg, LT, ws, ctx.nb, gcp, gcn, gsc, None, None, None, gRg), None, None
-
-
-def _fk_backward(hand, hp, ix, Rg, LT, ws, nb, gcp, gcn, gsc, wrench, gRt, gtheta, gR):
+@_custom_op("graspqp_amd::fk_contacts", mutates_args=(), device_types="cuda")
+def _fk_op(hand_pose: Tensor, idx: Tensor, hand: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """hand_pose, contact idx -> (Rg (B,3,3), link_T (B,L,3,4), contact_points, contact_normals, sphere_centers,
+    FK workspace holding the per-joint frames for the backward)."""
+    h = _handle(hand)
+    hp = _c(hand_pose)
+    ix = _c(idx, torch.int64)
     B, n = ix.shape
-    gp = torch.empty_like(hp)
-    _C.call("gq_fk_backward", hand.handle, _C.f32(hp), _C.i64(ix), B, n, _C.f32(Rg), _C.f32(LT),
-            _C.f32(None if gcp is None else _c(gcp)), _C.f32(None if gcn is None else _c(gcn)),
-            _C.f32(None if (gsc is None or hand.S == 0) else _c(gsc)), _C.f32(None if wrench is None else _c(wrench)),
-            _C.f32(None if gRt is None else _c(gRt)), _C.f32(None if gtheta is None else _c(gtheta)),
-            _C.f32(None if gR is None else _c(gR)), _C.f32(gp), None, None, _C.ptr(ws), nb, _C.stream_ptr())
+    dev = hp.device
+    Rg = torch.empty(B, 3, 3, device=dev)
+    LT = torch.empty(B, h.L, 3, 4, device=dev)
+    cp = torch.empty(B, n, 3, device=dev)
+    cn = torch.empty(B, n, 3, device=dev)
+    sc = torch.empty(B, max(h.S, 1), 3, device=dev)
+    ws, nb = h.fk_ws(B, dev)
+    _C.call("gq_fk_forward", h.handle, _C.f32(hp), _C.i64(ix), B, n, _C.f32(Rg), _C.f32(LT), _C.f32(cp),
+            _C.f32(cn), _C.f32(sc) if h.S > 0 else None, 0.0, None, None, None, None, _C.ptr(ws), nb, _C.stream_ptr())
+    return Rg, LT, cp, cn, sc[:, : h.S].contiguous(), ws
+
+
+@_fk_op.register_fake
+def _(hand_pose, idx, hand):
+    h = _handle(hand)
+    B, n = idx.shape
+    e = hand_pose.new_empty
+    return (e(B, 3, 3), e(B, h.L, 3, 4), e(B, n, 3), e(B, n, 3), e(B, h.S, 3), e(B * h.J * 18 * 4 + 256, dtype=torch.uint8))
+
+
+@_custom_op("graspqp_amd::fk_backward", mutates_args=(), device_types="cuda")
+def _fk_bwd_op(hand: int, hand_pose: Tensor, idx: Tensor, Rg: Tensor, LT: Tensor, ws: Tensor, gcp: Tensor, gcn: Tensor,
+               gsc: Tensor, wrench: Tensor, gRt: Tensor, gR: Tensor, has: List[bool]) -> Tensor:
+    """Analytic FK backward (replaces autograd through pytorch_kinematics).  ``has`` flags which of the six gradient
+    inputs (contact points, contact normals, sphere centres, link wrench, g_Rt, g_R) are present; absent ones are
+    passed as empty tensors (only tensors may cross the dispatcher)."""
+    h = _handle(hand)
+    B, n = idx.shape
+    gp = torch.empty_like(hand_pose)
+    opt = lambda t, on: _C.f32(_c(t)) if on else None
+    _C.call("gq_fk_backward", h.handle, _C.f32(hand_pose), _C.i64(idx), B, n, _C.f32(_c(Rg)), _C.f32(_c(LT)),
+            opt(gcp, has[0]), opt(gcn, has[1]), opt(gsc, has[2] and h.S > 0), opt(wrench, has[3]), opt(gRt, has[4]), None,
+            opt(gR, has[5]), _C.f32(gp), None, None, _C.ptr(ws), ws.numel(), _C.stream_ptr())
     return gp
+
+
+@_fk_bwd_op.register_fake
+def _(hand, hand_pose, idx, Rg, LT, ws, gcp, gcn, gsc, wrench, gRt, gR, has):
+    return torch.empty_like(hand_pose)
+
+
+def _fk_backward(hand, hp, ix, Rg, LT, ws, gcp=None, gcn=None, gsc=None, wrench=None, gRt=None, gR=None):
+    z = hp.new_empty(0)
+    args = [gcp, gcn, gsc, wrench, gRt, gR]
+    return torch.ops.graspqp_amd.fk_backward(hand.hid, hp, ix, Rg, LT, ws, *[z if a is None else a for a in args],
+                                             [a is not None for a in args])
+
+
+def _fk_setup(ctx, inputs, output):
+    ctx.save_for_backward(_c(inputs[0]), _c(inputs[1], torch.int64), output[0], output[1], output[5])
+    ctx.hand = inputs[2]
+
+
+def _fk_bwd(ctx, gRg, gLT, gcp, gcn, gsc, gws):
+    hp, ix, Rg, LT, ws = ctx.saved_tensors
+    # d / d link_T is routed through hand_pen's link wrenches, never through link_T itself: autograd hands a zero (or
+    # no) gradient here, which is ignored
+    return _fk_backward(_handle(ctx.hand), hp, ix, Rg, LT, ws, gcp, gcn, gsc, None, None, gRg), None, None
+
+
+torch.library.register_autograd("graspqp_amd::fk_contacts", _fk_bwd, setup_context=_fk_setup)
 
 
 def fk_contacts(hand_pose, idx, hand: HandHandle):
     """-> (Rg (B,3,3), link_T (B,L,3,4), contact_points, contact_normals, sphere_centers, fk workspace)."""
-    return _FK.apply(hand_pose, idx, hand)
+    if not hand_pose.is_cuda:
+        raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
+    return torch.ops.graspqp_amd.fk_contacts(hand_pose, idx, hand.hid)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -438,73 +585,116 @@ def root_pose_wxyz(hand_pose):
     return out
 
 
-class _HandPen(torch.autograd.Function):
-    """max-over-links signed distance (inside positive) of object surface points; differentiable w.r.t. hand_pose.
+@_custom_op("graspqp_amd::hand_pen", mutates_args=(), device_types="cuda")
+def _hand_pen_op(hand_pose: Tensor, surface_points: Tensor, batch_each: int, hand: int, Rg: Tensor, LT: Tensor,
+                 penetration_only: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """max-over-links signed distance (inside positive) of object surface points -> (dis (B,P), argmax link, d dis / d x_h).
 
-    The kinematic state (Rg, link_T, fk workspace) is passed in detached; the gradient is routed to ``hand_pose``
-    directly through the analytic FK backward (link wrenches), which is what autograd through
-    pytorch_kinematics computes in the reference (hand_model.py:875-987).
-    """
+    The kinematic state (Rg, link_T) is passed in detached; the gradient is routed to ``hand_pose`` directly through the
+    analytic FK backward (link wrenches), which is what autograd through pytorch_kinematics computes in the reference
+    (hand_model.py:875-987)."""
+    h = _handle(hand)
+    hp = _c(hand_pose)
+    sp = _c(surface_points)
+    n_obj, P, _ = sp.shape
+    B = hp.shape[0]
+    dev = hp.device
+    dis = torch.empty(B, P, device=dev)
+    link = torch.zeros(B, P, dtype=torch.int32, device=dev)  # mode 1 writes link / gvec only where dis > 0
+    gvec = torch.zeros(B, P, 3, device=dev)
+    pws, pnb = None, 0
+    if int(penetration_only) == 3:  # queue path without candidate lists (kept for A/B tests)
+        pnb = _size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), h.L)
+        pws = torch.zeros(pnb, dtype=torch.uint8, device=dev)  # queue counters must start at zero
+    _C.call("gq_hand_pen_forward", h.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
+            _C.f32(_c(Rg)), _C.f32(_c(LT)), int(penetration_only), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.ptr(pws), pnb,
+            None, None, _C.stream_ptr())
+    return dis, link, gvec
+
+
+@_hand_pen_op.register_fake
+def _(hand_pose, surface_points, batch_each, hand, Rg, LT, penetration_only):
+    B, P = hand_pose.shape[0], surface_points.shape[1]
+    return (hand_pose.new_empty(B, P), hand_pose.new_empty(B, P, dtype=torch.int32), hand_pose.new_empty(B, P, 3))
+
+
+@_custom_op("graspqp_amd::hand_pen_backward", mutates_args=(), device_types="cuda")
+def _hand_pen_bwd_op(n_links: int, surface_points: Tensor, batch_each: int, hand_pose: Tensor, Rg: Tensor, g: Tensor,
+                     link: Tensor, gvec: Tensor) -> Tuple[Tensor, Tensor]:
+    sp = _c(surface_points)
+    n_obj, P, _ = sp.shape
+    B = hand_pose.shape[0]
+    wrench = torch.empty(B, n_links, 6, device=g.device)
+    gRt = torch.empty(B, 12, device=g.device)
+    _C.call("gq_hand_pen_backward", int(n_links), _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hand_pose), hand_pose.shape[1],
+            _C.f32(_c(Rg)), _C.f32(_c(g)), _C.i32(link), _C.f32(gvec), _C.f32(wrench), _C.f32(gRt), None, 0.0, None, None, None,
+            _C.stream_ptr())
+    return wrench, gRt
+
+
+@_hand_pen_bwd_op.register_fake
+def _(n_links, surface_points, batch_each, hand_pose, Rg, g, link, gvec):
+    B = hand_pose.shape[0]
+    return hand_pose.new_empty(B, n_links, 6), hand_pose.new_empty(B, 12)
+
+
+def hand_pen(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb=None, penetration_only=False):
+    """(B,P) max-over-links signed distance, differentiable w.r.t. hand_pose (see the op's docstring)."""
+    return _HandPen.apply(hand_pose, surface_points, int(batch_each), hand, idx, Rg.detach(), LT.detach(), ws,
+                          int(penetration_only))
+
+
+class _HandPen(torch.autograd.Function):
+    """Glue between two registered ops (hand_pen + fk_backward): the backward needs the hand's FK workspace and contact
+    indices, which are not inputs of the distance query itself."""
 
     @staticmethod
-    def forward(ctx, hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only=False):
+    def forward(ctx, hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, penetration_only):
         hp = _c(hand_pose.detach())
         sp = _c(surface_points)
-        n_obj, P, _ = sp.shape
-        B = hp.shape[0]
-        dev = hp.device
-        dis = torch.empty(B, P, device=dev)
-        link = torch.zeros(B, P, dtype=torch.int32, device=dev)  # mode 1 writes link / gvec only where dis > 0
-        gvec = torch.zeros(B, P, 3, device=dev)
-        pws, pnb = None, 0
-        if int(penetration_only) == 3:  # queue path without candidate lists (kept for A/B tests)
-            pnb = _size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), hand.L)
-            pws = torch.zeros(pnb, dtype=torch.uint8, device=dev)  # queue counters must start at zero
-        _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
-                _C.f32(Rg), _C.f32(LT), int(penetration_only), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.ptr(pws), pnb,
-                None, None, _C.stream_ptr())
+        dis, link, gvec = torch.ops.graspqp_amd.hand_pen(hp, sp, batch_each, hand.hid, Rg, LT, penetration_only)
         ctx.save_for_backward(hp, sp, idx, Rg, LT, ws, link, gvec)
-        ctx.hand, ctx.batch_each, ctx.nb = hand, int(batch_each), nb
+        ctx.hand, ctx.batch_each = hand, batch_each
         return dis
 
     @staticmethod
     def backward(ctx, g):
         hp, sp, idx, Rg, LT, ws, link, gvec = ctx.saved_tensors
         hand = ctx.hand
-        n_obj, P, _ = sp.shape
-        B = hp.shape[0]
-        dev = hp.device
-        wrench = torch.empty(B, hand.L, 6, device=dev)
-        gRt = torch.empty(B, 12, device=dev)
-        _C.call("gq_hand_pen_backward", hand.L, _C.f32(sp), n_obj, P, ctx.batch_each, _C.f32(hp), hp.shape[1], _C.f32(Rg),
-                _C.f32(_c(g)), _C.i32(link), _C.f32(gvec), _C.f32(wrench), _C.f32(gRt), None, 0.0, None, None, None,
-                _C.stream_ptr())
-        gp = _fk_backward(hand, hp, idx, Rg, LT, ws, ctx.nb, None, None, None, wrench, gRt, None, None)
-        return gp, None, None, None, None, None, None, None, None, None
+        wrench, gRt = torch.ops.graspqp_amd.hand_pen_backward(hand.L, sp, ctx.batch_each, hp, Rg, g, link, gvec)
+        gp = _fk_backward(hand, hp, idx, Rg, LT, ws, None, None, None, wrench, gRt, None)
+        return gp, None, None, None, None, None, None, None, None
 
 
-def hand_pen(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only=False):
-    return _HandPen.apply(hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, nb, penetration_only)
+@_custom_op("graspqp_amd::self_pen", mutates_args=(), device_types="cuda")
+def _self_pen_op(centers: Tensor, hand: int) -> Tuple[Tensor, Tensor]:
+    """E_spen (B,) of world sphere centres (B,S,3) and dE/dcentres (hand_model.py:989-1040)."""
+    c = _c(centers)
+    B = c.shape[0]
+    e = torch.empty(B, device=c.device)
+    g = torch.empty_like(c)
+    _C.call("gq_self_pen_forward", _handle(hand).handle, _C.f32(c), B, 1.0, _C.f32(e), _C.f32(g), _C.stream_ptr())
+    return e, g
 
 
-class _SelfPen(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, centers, hand):
-        c = _c(centers.detach())
-        B = c.shape[0]
-        e = torch.empty(B, device=c.device)
-        g = torch.empty_like(c)
-        _C.call("gq_self_pen_forward", hand.handle, _C.f32(c), B, 1.0, _C.f32(e), _C.f32(g), _C.stream_ptr())
-        ctx.save_for_backward(g)
-        return e
+@_self_pen_op.register_fake
+def _(centers, hand):
+    return centers.new_empty(centers.shape[0]), torch.empty_like(centers)
 
-    @staticmethod
-    def backward(ctx, ge):
-        (g,) = ctx.saved_tensors
-        return g * ge.view(-1, 1, 1), None
+
+def _self_pen_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _self_pen_bwd(ctx, ge, gg):
+    (g,) = ctx.saved_tensors
+    return g * ge.view(-1, 1, 1), None
+
+
+torch.library.register_autograd("graspqp_amd::self_pen", _self_pen_bwd, setup_context=_self_pen_setup)
 
 
 def self_pen(centers, hand: HandHandle):
     if hand.S == 0:
         return torch.zeros(centers.shape[0], device=centers.device)
-    return _SelfPen.apply(centers, hand)
+    return torch.ops.graspqp_amd.self_pen(centers, hand.hid)[0]

@@ -116,3 +116,86 @@ def test_descriptor_struct_layouts_match_the_header(tmp_path):
         cls = pairs[name]
         want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(x) for x in nums] == want, f"{name}: C {nums} vs ctypes {want}"
+
+
+def test_solver_cls_is_honoured_or_refused_loudly():
+    """reference span.py:23-37,299 / registry.py:112: `solver_cls` selects the QP back end.  The HIP class is accepted, a
+    foreign one is refused (never silently replaced)."""
+    from graspqp_amd.metrics import SpanMetricWrapper, SQPLsqSolver
+    from graspqp_amd.metrics.ops.span import OverallFrictionConeSpanMetric
+
+    class Foreign:
+        pass
+
+    class Mine(SQPLsqSolver):
+        pass
+
+    OverallFrictionConeSpanMetric(solver_cls=SQPLsqSolver)
+    OverallFrictionConeSpanMetric.from_dim(48, 6, solver_cls=Mine, friction=0.2, n_cone_vecs=4)
+    with pytest.raises(NotImplementedError, match="solver_cls"):
+        OverallFrictionConeSpanMetric(solver_cls=Foreign)
+    w = SpanMetricWrapper(OverallFrictionConeSpanMetric, metric_kwargs={"solver_cls": Foreign, "friction": 0.2})
+    with pytest.raises(NotImplementedError, match="solver_cls"):
+        w(torch.zeros(2, 4, 3), torch.zeros(2, 4, 3), torch.zeros(2, 3))
+
+
+def test_ops_are_registered_with_the_dispatcher():
+    """north_star: "exposed as torch ops" -- torch.library custom ops with fake kernels (traceable) and autograd."""
+    from graspqp_amd import ops  # noqa: F401
+
+    ns = torch.ops.graspqp_amd
+    for name in ("compute_sdf", "sdf_backward", "sdf_meshset", "box_qp", "box_qp_backward", "lsq_box_qp", "lsq_box_qp_backward",
+                 "fc_energy", "fc_energy_backward", "fk_contacts", "fk_backward", "hand_pen", "hand_pen_backward", "self_pen"):
+        assert hasattr(ns, name), name
+    # fake (meta) kernels: shapes without touching a GPU
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    with FakeTensorMode():
+        pts, fv = torch.empty(7, 3, device="cuda"), torch.empty(20, 3, 3, device="cuda")
+        d2, sgn, nrm, cls = ns.compute_sdf(pts, fv)
+        assert d2.shape == (7,) and sgn.dtype == torch.int32 and cls.shape == (7, 3)
+        x, lam, slack, nit = ns.lsq_box_qp(torch.empty(5, 6, 48, device="cuda"), torch.empty(5, 6, device="cuda"), 1.0, 21.0,
+                                           1e-4, 5e-2, 12)
+        assert x.shape == (5, 48) and lam.shape == (5, 96)
+    # no CPU kernel: a CPU tensor is refused by the dispatcher
+    with pytest.raises(NotImplementedError):
+        ns.compute_sdf(torch.zeros(4, 3), torch.zeros(2, 3, 3))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/graspqp/src/graspqp"), reason="needs the reference tree (build container)")
+def test_integration_aliases_import_the_reference_modules():
+    """INTEGRATION.md sections 1-2: with `torchsdf` and `qpth` aliased to graspqp_amd, the reference's own
+    metrics/solver/qp_solver.py imports and builds its solver around OUR QPFunction (no compute without a GPU)."""
+    import importlib.util
+    import sys
+    import types
+
+    import graspqp_amd.metrics
+    import graspqp_amd.torchsdf
+
+    saved = {k: sys.modules.get(k) for k in ("torchsdf", "qpth", "qpth.qp")}
+    try:
+        sys.modules["torchsdf"] = graspqp_amd.torchsdf
+        qp = types.ModuleType("qpth.qp")
+        qp.QPFunction = graspqp_amd.metrics.QPFunction
+        pkg = types.ModuleType("qpth")
+        pkg.qp = qp
+        sys.modules["qpth"], sys.modules["qpth.qp"] = pkg, qp
+        from torchsdf import compute_sdf, index_vertices_by_faces
+
+        assert compute_sdf is graspqp_amd.torchsdf.compute_sdf
+        assert index_vertices_by_faces(torch.arange(12.0).view(4, 3), torch.tensor([[0, 1, 2]])).shape == (1, 3, 3)
+        spec = importlib.util.spec_from_file_location(
+            "_ref_qp_solver", "/root/reference/graspqp/src/graspqp/metrics/solver/qp_solver.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.dont_write_bytecode = True
+        spec.loader.exec_module(mod)
+        assert mod.QPFunction is graspqp_amd.metrics.QPFunction
+        solver = mod.SQPLsqSolver.from_mat(torch.zeros(2, 6, 48), torch.zeros(2, 6))
+        assert solver._batch_size == 2
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -744,3 +744,85 @@ def test_mala_clip_grad_with_nan_inf_matches_reference_optimizer(gq, golden_dir)
         st.step(draws=draws("C_s2"))
         torch.cuda.synchronize()
         _check_iteration(st, g, "C_s2")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# boundary: dispatcher-registered ops, the reference-shaped metric call with solver_cls, contact candidates
+# ---------------------------------------------------------------------------------------------------------------
+def test_torch_library_ops_opcheck(gq, golden_dir):
+    """torch.library.opcheck on the registered ops: schema (no undeclared mutation / aliasing), fake kernels consistent
+    with the real ones, autograd registered through the dispatcher."""
+    g = _load(golden_dir, "span_n4_k4.npz")
+    utils = ("test_schema", "test_autograd_registration", "test_faketensor")
+    ns = torch.ops.graspqp_amd
+    pts = torch.randn(33, 3, device="cuda").mul(0.05).requires_grad_()
+    fv = torch.tensor(meshes.box(), device="cuda")
+    torch.library.opcheck(ns.compute_sdf, (pts, fv), test_utils=utils)
+    F = torch.tensor(g["F"], dtype=torch.float32).cuda().requires_grad_()
+    torch.library.opcheck(ns.lsq_box_qp, (F, torch.zeros(F.shape[0], 6, device="cuda"), 1.0, 21.0, 1e-4, 5e-2, 12), test_utils=utils)
+    cp = torch.tensor(g["contact_pts"], dtype=torch.float32).cuda().requires_grad_()
+    cn = torch.tensor(g["contact_normals"], dtype=torch.float32).cuda()
+    cog = torch.tensor(g["cog"], dtype=torch.float32).cuda()
+    torch.library.opcheck(ns.fc_energy, (cp, cn, cog, 4, 0.2, 5.0, 20.0, 0.1, 2.0, 5e-2, 12), test_utils=utils)
+    hand = gq.ops.HandHandle(get_hand_spec("allegro"))
+    hp = _rand_pose(hand.spec, 3, 5).float().cuda().requires_grad_()
+    idx = torch.randint(hand.spec.n_contact_candidates, (3, 4), device="cuda")
+    torch.library.opcheck(ns.fk_contacts, (hp, idx, hand.hid), test_utils=utils)
+    # the dispatcher route gives the same numbers and gradients as the wrapper functions
+    e, xs = gq.ops.fc_energy(cp, cn, cog, n_cone_vecs=4)
+    e2, xs2, nit, _ = ns.fc_energy(cp, cn, cog, 4, 0.2, 5.0, 20.0, 0.1, 2.0, 5e-2, 12)
+    assert torch.equal(e, e2) and torch.equal(xs, xs2) and int(nit) >= 1
+    (g1,) = torch.autograd.grad(e.sum(), cp)
+    (g2,) = torch.autograd.grad(e2.sum(), cp)
+    assert torch.equal(g1, g2)
+
+
+def test_reference_shaped_metric_call_with_solver_cls(gq, golden_dir):
+    """SpanMetricWrapper driven the way the reference's factory builds it (registry.py:108-118:
+    metric class + metric_kwargs incl. solver_cls), against the factory shortcut and the fixture; a foreign solver_cls is
+    refused."""
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+    from graspqp_amd.metrics import SpanMetricWrapper, SQPLsqSolver
+    from graspqp_amd.metrics.ops.span import OverallFrictionConeSpanMetric
+
+    g = _load(golden_dir, "span_n12_k4.npz")
+    pts, nrm, cog = (torch.tensor(g[k], dtype=torch.float32).cuda() for k in ("contact_pts", "contact_normals", "cog"))
+    fn = SpanMetricWrapper(OverallFrictionConeSpanMetric,
+                           metric_kwargs={"solver_cls": SQPLsqSolver, "friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+    p1 = pts.clone().requires_grad_()
+    e1, x1 = fn(contact_pts=p1, contact_normals=nrm, sdf=None, cog=cog, with_solution=True, svd_gain=0.1)
+    e2, x2 = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})(
+        contact_pts=pts, contact_normals=nrm, sdf=None, cog=cog, with_solution=True, svd_gain=0.1)
+    assert torch.equal(e1.detach(), e2) and torch.equal(x1, x2)
+    e1.sum().backward()
+    assert torch.isfinite(p1.grad).all() and p1.grad.abs().sum() > 0
+    # the metric class itself, reference-shaped: (res, basis, svd_scales, values)
+    m = OverallFrictionConeSpanMetric.from_dim(48, 6, batch_size=pts.shape[0], solver_cls=SQPLsqSolver, friction=0.2, n_cone_vecs=4)
+    m._max_limit_value = 20.0
+    res, basis, svd, xs = m(pts, nrm, cog)
+    np.testing.assert_allclose(svd.squeeze(-1).cpu().numpy(), g["svd"], rtol=2e-3)
+    np.testing.assert_allclose((2 * (res.squeeze(-1) + 0.01) * torch.exp(-0.1 * svd.squeeze(-1))).cpu().numpy(),
+                               e2.cpu().numpy(), rtol=1e-4)
+
+    class Foreign:
+        pass
+
+    with pytest.raises(NotImplementedError, match="solver_cls"):
+        SpanMetricWrapper(OverallFrictionConeSpanMetric, metric_kwargs={"solver_cls": Foreign})(pts, nrm, cog)
+
+
+def test_get_contact_candidates_matches_oracle(gq):
+    from graspqp_amd.core.hand_model import HandModel
+
+    spec = get_hand_spec("shadow_hand")
+    hp = _rand_pose(spec, 4, 9)
+    oh = omodels.OracleHand(spec, torch.float64)
+    oh.set_parameters(hp, torch.zeros(4, 2, dtype=torch.long))
+    pw, nw = okin.contact_candidates_world(spec, oh.current_status, oh.global_rotation, oh.global_translation)
+    hm = HandModel(spec, "cuda")
+    hm.set_parameters(hp.float().cuda(), torch.zeros(4, 2, dtype=torch.long).cuda())
+    cp, cn = hm.get_contact_candidates(with_normals=True)
+    assert cp.shape == (4, spec.n_contact_candidates, 3)
+    np.testing.assert_allclose(cp.cpu().numpy(), pw.numpy(), atol=3e-6)
+    np.testing.assert_allclose(cn.cpu().numpy(), nw.numpy(), atol=3e-6)
+    assert torch.equal(hm.get_contact_candidates(), cp)

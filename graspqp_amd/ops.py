@@ -139,6 +139,7 @@ def _(points, face_verts):
 
 def _sdf_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]), output[3])
+    ctx.mark_non_differentiable(output[1], output[2], output[3])  # TorchSDF: only dist_sq is differentiable
 
 
 def _sdf_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
@@ -178,6 +179,7 @@ def _(points, meshset, queries_per_mesh):
 def _sdf_ms_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]).reshape(-1, 3), output[3])
     ctx.in_shape = inputs[0].shape
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
 
 
 def _sdf_ms_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
@@ -240,6 +242,7 @@ def _(Q, lam, slack, gx):
 
 def _box_qp_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]), output[0], output[1], output[2])
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
 
 
 def _box_qp_bwd(ctx, gx, g_lam, g_slack, g_nit):
@@ -302,6 +305,7 @@ def _(A, lam, slack, gx, ridge):
 def _lsq_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]), _c(inputs[1]), output[0], output[1], output[2])
     ctx.ridge = inputs[4]
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
 
 
 def _lsq_bwd(ctx, gx, g_lam, g_slack, g_nit):
@@ -373,6 +377,7 @@ def _(contact_pts, contact_normals, cog, ge, ws, n_cone_vecs, friction, torque_w
 def _fc_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]), _c(inputs[1]), _c(inputs[2]), output[3])
     ctx.cfg = inputs[3:]
+    ctx.mark_non_differentiable(output[1], output[2], output[3])
 
 
 def _fc_bwd(ctx, ge, g_xs, g_nit, g_ws):
@@ -519,6 +524,7 @@ def _fk_backward(hand, hp, ix, Rg, LT, ws, gcp=None, gcn=None, gsc=None, wrench=
 def _fk_setup(ctx, inputs, output):
     ctx.save_for_backward(_c(inputs[0]), _c(inputs[1], torch.int64), output[0], output[1], output[5])
     ctx.hand = inputs[2]
+    ctx.mark_non_differentiable(output[5])
 
 
 def _fk_bwd(ctx, gRg, gLT, gcp, gcn, gsc, gws):
@@ -684,6 +690,7 @@ def _(centers, hand):
 
 def _self_pen_setup(ctx, inputs, output):
     ctx.save_for_backward(output[1])
+    ctx.mark_non_differentiable(output[1])
 
 
 def _self_pen_bwd(ctx, ge, gg):

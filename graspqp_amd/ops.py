@@ -354,8 +354,9 @@ def _fc_energy_op(contact_pts: Tensor, contact_normals: Tensor, cog: Tensor, n_c
 @_fc_energy_op.register_fake
 def _(contact_pts, contact_normals, cog, n_cone_vecs, friction, torque_weight, max_limit, svd_gain, values_gain, eps, max_iter):
     B, n, _ = contact_pts.shape
+    nb = _size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, int(n_cone_vecs), int(max_iter))  # host-only helper
     return (contact_pts.new_empty(B), contact_pts.new_empty(B, n), contact_pts.new_empty(1, dtype=torch.int32),
-            contact_pts.new_empty(1, dtype=torch.uint8))
+            contact_pts.new_empty(nb, dtype=torch.uint8))
 
 
 @_custom_op("graspqp_amd::fc_energy_backward", mutates_args=("ws",), device_types="cuda")  # scratch inside the workspace
@@ -490,7 +491,8 @@ def _(hand_pose, idx, hand):
     h = _handle(hand)
     B, n = idx.shape
     e = hand_pose.new_empty
-    return (e(B, 3, 3), e(B, h.L, 3, 4), e(B, n, 3), e(B, n, 3), e(B, h.S, 3), e(B * h.J * 18 * 4 + 256, dtype=torch.uint8))
+    nb = _size_call("gq_fk_workspace_bytes", h.handle, ctypes.c_int64(B))
+    return (e(B, 3, 3), e(B, h.L, 3, 4), e(B, n, 3), e(B, n, 3), e(B, h.S, 3), e(nb, dtype=torch.uint8))
 
 
 @_custom_op("graspqp_amd::fk_backward", mutates_args=(), device_types="cuda")

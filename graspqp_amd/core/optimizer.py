@@ -117,3 +117,21 @@ class MalaStar:
     def zero_grad(self):
         if self.hand_model.hand_pose.grad is not None:
             self.hand_model.hand_pose.grad.data.zero_()
+
+
+class AnnealingDexGraspNet(MalaStar):
+    """DexGraspNet's annealing optimiser with the reference's surface (core/optimizer.py:11-149): the same RMS-normalised
+    proposal and Metropolis test as MalaStar on the same HIP kernels, but one global step counter, no gradient clipping,
+    no z-score in the temperature, and re-initialisations are not tracked (``reset_envs`` is a no-op, ``accept_step``
+    ignores ``reset_mask`` / ``z_score``)."""
+
+    def __init__(self, hand_model, switch_possibility=0.5, starting_temperature=18, temperature_decay=0.95,
+                 annealing_period=30, step_size=0.005, stepsize_period=50, mu=0.98, device="cuda", generator=None, **kwargs):
+        super().__init__(hand_model, switch_possibility, starting_temperature, temperature_decay, annealing_period, step_size,
+                         stepsize_period, mu, device, clip_grad=False, generator=generator)
+
+    def reset_envs(self, mask):
+        pass
+
+    def accept_step(self, energy, new_energy, *args, u_accept=None, **kwargs):
+        return super().accept_step(energy, new_energy, None, None, u_accept=u_accept)

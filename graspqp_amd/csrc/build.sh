@@ -20,13 +20,14 @@ deps() {  # headers each translation unit includes
     sdf) echo "common.h tri.h pen_dev.h sdf_dev.h wave.h" ;;
     fc) echo "common.h fc_dev.h wave.h" ;;
     loop) echo "common.h fc_dev.h loop_dev.h wave.h" ;;
+    metric) echo "common.h wave.h" ;;
     init) echo "common.h wave.h" ;;
     export) echo "common.h kin_dev.h wave.h" ;;
     kin) echo "common.h loop_dev.h sdf_dev.h tri.h kin_dev.h wave.h" ;;
     *) echo "common.h" ;;
   esac
 }
-for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep stage loop export init; do
+for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep stage loop export init metric; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done

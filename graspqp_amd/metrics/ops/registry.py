@@ -81,7 +81,15 @@ class GraspSpanMetricFactory:
                     **solver_kwargs,
                 },
             )
+        if metric_type == MT.DEXGRASP:  # registry.py:104-105
+            from .dexgrasp import DexgraspSpanMetric
+
+            return DexgraspSpanMetric()
+        if metric_type == MT.TDG:  # registry.py:106-107
+            from .tdg import TDGSpanMetric
+
+            return TDGSpanMetric(device="cuda")
         raise NotImplementedError(
-            f"{metric_type}: only MetricType.GRASPQP is accelerated here; the other energy types of the reference "
-            "are plain torch modules and run unchanged on PyTorch-ROCm (out of scope, SURVEY 8f-3)"
+            f"{metric_type}: the scipy-backed variants (GRASPQP_SCIPY, GRASPQP_EUCLIDIAN_SCIPY) are CPU solvers the "
+            "reference keeps for visualisation only; graspqp_amd has no CPU path"
         )

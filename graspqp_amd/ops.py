@@ -406,6 +406,69 @@ def fc_energy(contact_pts, contact_normals, cog, return_n_iter=False, **cfg):
     return (e, xs, nit) if return_n_iter else (e, xs)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# the reference's other force-closure energies: dexgrasp (||G'n||^2) and TDG (grasp-wrench-space directions)
+# ----------------------------------------------------------------------------------------------------------
+@_custom_op("graspqp_amd::dexgrasp_energy", mutates_args=(), device_types="cuda")
+def _dexgrasp_op(contact_pts: Tensor, contact_normals: Tensor, cog: Tensor, torque_weight: float) -> Tuple[Tensor, Tensor]:
+    """-> (E (B), dE/d contact_pts (B,n,3)); metrics/ops/dexgrasp.py:4-34."""
+    cp, cn, cg = _c(contact_pts), _c(contact_normals), _c(cog)
+    B, n, _ = cp.shape
+    e = torch.empty(B, device=cp.device)
+    g = torch.empty_like(cp)
+    _C.call("gq_dexgrasp_energy", _C.f32(cp), _C.f32(cn), _C.f32(cg), ctypes.c_int64(B), n, float(torque_weight), None, 1.0, 0,
+            _C.f32(e), _C.f32(g), _C.stream_ptr())
+    return e, g
+
+
+@_dexgrasp_op.register_fake
+def _(contact_pts, contact_normals, cog, torque_weight):
+    return contact_pts.new_empty(contact_pts.shape[0]), torch.empty_like(contact_pts)
+
+
+@_custom_op("graspqp_amd::tdg_energy", mutates_args=(), device_types="cuda")
+def _tdg_op(contact_pts: Tensor, contact_normals: Tensor, cog: Tensor, directions: Tensor, friction: float, obb_length: float,
+            enable_density: bool, scale: float) -> Tuple[Tensor, Tensor]:
+    """-> (E (B), dE/d contact_pts (B,n,3)); metrics/ops/tdg.py:147-239."""
+    cp, cn, cg, dr = _c(contact_pts), _c(contact_normals), _c(cog), _c(directions)
+    B, n, _ = cp.shape
+    e = torch.empty(B, device=cp.device)
+    g = torch.empty_like(cp)
+    _C.call("gq_tdg_energy", _C.f32(cp), _C.f32(cn), _C.f32(cg), _C.f32(dr), dr.shape[0], ctypes.c_int64(B), n, float(friction),
+            float(obb_length), int(bool(enable_density)), float(scale), None, 1.0, 0, _C.f32(e), _C.f32(g), _C.stream_ptr())
+    return e, g
+
+
+@_tdg_op.register_fake
+def _(contact_pts, contact_normals, cog, directions, friction, obb_length, enable_density, scale):
+    return contact_pts.new_empty(contact_pts.shape[0]), torch.empty_like(contact_pts)
+
+
+def _alt_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.n_in = len(inputs)
+    ctx.mark_non_differentiable(output[1])
+
+
+def _alt_bwd(ctx, ge, gg):
+    (g,) = ctx.saved_tensors
+    return (g * ge.view(-1, 1, 1),) + (None,) * (ctx.n_in - 1)
+
+
+torch.library.register_autograd("graspqp_amd::dexgrasp_energy", _alt_bwd, setup_context=_alt_setup)
+torch.library.register_autograd("graspqp_amd::tdg_energy", _alt_bwd, setup_context=_alt_setup)
+
+
+def dexgrasp_energy(contact_pts, contact_normals, cog, torque_weight=0.0):
+    """(B,) DexGraspNet force-closure term; gradient to contact_pts (the normals are SDF constants)."""
+    return torch.ops.graspqp_amd.dexgrasp_energy(contact_pts, contact_normals.detach(), cog.detach(), float(torque_weight))[0]
+
+
+def tdg_energy(contact_pts, contact_normals, cog, directions, friction=0.2, obb_length=0.2, enable_density=True, scale=100.0):
+    return torch.ops.graspqp_amd.tdg_energy(contact_pts, contact_normals.detach(), cog.detach(), directions, float(friction),
+                                            float(obb_length), bool(enable_density), float(scale))[0]
+
+
 def fc_peek(ws, B, n, k):
     """(F, x, val, svd) views of the last fc_energy forward on workspace ``ws`` (tests)."""
     outs = [ctypes.c_void_p(0) for _ in range(4)]

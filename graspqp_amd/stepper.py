@@ -26,7 +26,14 @@ DEFAULT_WEIGHTS = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, 
 class GraspStepper:
     def __init__(self, hand: ops.HandHandle, object_meshes: ops.MeshSet, surface_points: torch.Tensor, batch_each: int,
                  n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
-                 penetration_only: bool = True):
+                 penetration_only: bool = True, energy_type: str = "graspqp", optimizer: str = "mala_star",
+                 tdg_directions=None):
+        """energy_type: "graspqp" (default; the fused launches) | "dexgrasp" | "tdg" (scripts/fit.py:343-347; the
+        force-closure term is then one extra launch after the contact terms).  optimizer: "mala_star" | "dexgraspnet"
+        (AnnealingDexGraspNet, core/optimizer.py:11-149: no z-score in the temperature, no re-initialisation)."""
+        if energy_type not in ("graspqp", "dexgrasp", "tdg") or optimizer not in ("mala_star", "dexgraspnet"):
+            raise NotImplementedError(f"energy_type={energy_type!r} / optimizer={optimizer!r}")
+        self.energy_type, self.optimizer = energy_type, optimizer
         self.hand, self.objs = hand, object_meshes
         self.dev = torch.device(device)
         self.surf = surface_points.to(self.dev, torch.float32).contiguous()  # (n_obj,P,3)
@@ -99,6 +106,14 @@ class GraspStepper:
         self._span_acc = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self._side = None
         self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
+        self._can_fuse = self.penetration_only == 1 and energy_type == "graspqp"
+        self.tdg_dirs = None
+        if energy_type == "tdg":
+            if tdg_directions is None:
+                from .metrics.ops.tdg import random_sample_points_on_sphere
+
+                tdg_directions = random_sample_points_on_sphere(3, 1000)
+            self.tdg_dirs = torch.as_tensor(tdg_directions, dtype=torch.float32).to(self.dev).contiguous()
         e = _C.RowEnergyDesc()
         e.dist_sq, e.sign, e.obj_dir, e.hand_normals = (t.data_ptr() for t in (self.d2, self.sgn, self.onrm, self.cnrm))
         e.joints_lower, e.joints_upper = self.jlo.data_ptr(), self.jhi.data_ptr()
@@ -145,7 +160,8 @@ class GraspStepper:
         pr.mu, pr.switch_possibility, pr.clip_grad = float(m["mu"]), float(m["switch_possibility"]), int(bool(m["clip_grad"]))
         pr.slot_ctr, pr.slots = self._slot_ctr.data_ptr(), 64
         ac = _C.AcceptDesc()
-        ac.u_accept, ac.z, ac.reset_mask, ac.step = self._u_ac.data_ptr(), self.z.data_ptr(), None, self.step_count.data_ptr()
+        ac.u_accept, ac.reset_mask, ac.step = self._u_ac.data_ptr(), None, self.step_count.data_ptr()
+        ac.z = self.z.data_ptr() if optimizer == "mala_star" else None  # AnnealingDexGraspNet: plain annealing
         ac.starting_temperature, ac.decay, ac.annealing_period = (float(m["starting_temperature"]), float(m["temperature_decay"]),
                                                                   int(m["annealing_period"]))
         ac.energy, ac.pose, ac.idx, ac.grad = (t.data_ptr() for t in (self.energy, self.hand_pose, self.contact_idx, self.grad))
@@ -179,6 +195,17 @@ class GraspStepper:
         e_fc = self.terms_new[1]
         C("gq_sdf_forward_meshset", self.objs.handle, f32(self.cpts), B * n, self.be * n, f32(self.d2), i32(self.sgn),
           f32(self.onrm), f32(self.closest), st)
+        if self.energy_type != "graspqp":
+            # E_dis terms (+ outward object normals), then the other force-closure energy adds w_fc dE/dp in one launch
+            C("gq_contact_terms", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.closest), f32(self.cpts),
+              f32(self.cnrm), ctypes.c_int64(B), n, float(w["E_dis"]), f32(self.obj_normal), f32(self.g_cpts), f32(self.g_cnrm), st)
+            if self.energy_type == "dexgrasp":  # torque_weight = 0 at the reference's call site (core/energy.py:35-42)
+                C("gq_dexgrasp_energy", f32(self.cpts), f32(self.obj_normal), f32(self.cog), ctypes.c_int64(B), n, 0.0, None,
+                  float(w["E_fc"]), 1, f32(e_fc), f32(self.g_cpts), st)
+            else:
+                C("gq_tdg_energy", f32(self.cpts), f32(self.obj_normal), f32(self.cog), f32(self.tdg_dirs), self.tdg_dirs.shape[0],
+                  ctypes.c_int64(B), n, 0.2, 0.2, 1, 100.0, None, float(w["E_fc"]), 1, f32(e_fc), f32(self.g_cpts), st)
+            return
         C("gq_fc_step", f32(self.d2), i32(self.sgn), f32(self.onrm), f32(self.closest), f32(self.cpts), f32(self.cnrm),
           f32(self.cog), B, n, int(fc["n_cone_vecs"]), float(fc["friction"]), float(fc["torque_weight"]),
           float(fc["max_limit"]), float(fc["svd_gain"]), float(fc["values_gain"]), float(fc["eps"]), int(fc["max_iter"]),
@@ -282,7 +309,7 @@ class GraspStepper:
     def _accept(self, st):
         B, D, n, m = self.B, self.D, self.n, self.mala
         C, f32, i64 = _C.call, _C.f32, _C.i64
-        C("gq_mala_accept", f32(self.total_new), f32(self._cur[2]), f32(self.z), None,
+        C("gq_mala_accept", f32(self.total_new), f32(self._cur[2]), f32(self.z) if self.optimizer == "mala_star" else None, None,
           i64(self.step_count), f32(self.pose_new), i64(self.idx_new), f32(self.grad_new), B, D, n,
           float(m["starting_temperature"]), float(m["temperature_decay"]), int(m["annealing_period"]), f32(self.energy),
           f32(self.hand_pose), i64(self.contact_idx), f32(self.grad), _C.u8(self.accept), f32(self.temperature), 5,
@@ -386,18 +413,20 @@ class GraspStepper:
         # masked merges with torch.where: boolean-mask indexing would synchronise with the host
         self.pose_new.copy_(torch.where(mc, new_pose.to(self.dev, torch.float32), self.pose_new))
         self.idx_new.copy_(torch.where(mc, idx_all, self.idx_new))
-        self.step_count.masked_fill_(m, 0)  # optimizer.py:275-284
-        self.ema.masked_fill_(mc, 0.0)
-        self.hand_pose.copy_(torch.where(mc, self.pose_new, self.hand_pose))
-        self.contact_idx.copy_(torch.where(mc, self.idx_new, self.contact_idx))
-        self.grad.masked_fill_(mc, 0.0)
+        mala = self.optimizer == "mala_star"
+        if mala:  # MalaStar.reset_envs (optimizer.py:275-284); AnnealingDexGraspNet.reset_envs is a no-op (:148-149)
+            self.step_count.masked_fill_(m, 0)
+            self.ema.masked_fill_(mc, 0.0)
+            self.hand_pose.copy_(torch.where(mc, self.pose_new, self.hand_pose))
+            self.contact_idx.copy_(torch.where(mc, self.idx_new, self.contact_idx))
+            self.grad.masked_fill_(mc, 0.0)
         # reference quirk (hand_model.py:815-831): set_parameters(..., env_mask) gathers the contact points of ALL rows with
         # the freshly drawn indices it is handed (initializations.py:190-193), while the rows outside the mask keep
         # their proposal's indices as state -- so this iteration's energies are evaluated at ``new_idx`` everywhere
         self._evaluate(self.pose_new, idx_all, st)
-        rm = m.to(torch.uint8).contiguous()
+        rm = m.to(torch.uint8).contiguous() if mala else None  # AnnealingDexGraspNet.accept_step ignores reset_mask
         B, D, n, mc = self.B, self.D, self.n, self.mala
-        _C.call("gq_mala_accept", _C.f32(self.total_new), _C.f32(self._cur[2]), _C.f32(self.z), _C.u8(rm),
+        _C.call("gq_mala_accept", _C.f32(self.total_new), _C.f32(self._cur[2]), _C.f32(self.z) if mala else None, _C.u8(rm),
                 _C.i64(self.step_count), _C.f32(self.pose_new), _C.i64(self.idx_new), _C.f32(self.grad_new), B, D, n,
                 float(mc["starting_temperature"]), float(mc["temperature_decay"]), int(mc["annealing_period"]),
                 _C.f32(self.energy), _C.f32(self.hand_pose), _C.i64(self.contact_idx), _C.f32(self.grad),
@@ -457,7 +486,7 @@ class GraspStepper:
         if self._graph_pending:
             st = _C.stream_ptr()
             for _ in range(self._graph_pending):
-                self._iteration(st, fused=self.penetration_only == 1)
+                self._iteration(st, fused=self._can_fuse)
             self._graph_pending = 0
 
     def capture(self, fork=False, fused=True, iters=1):
@@ -473,7 +502,7 @@ class GraspStepper:
                 self._span_acc, self._slot_ctr)
         saved = [t.clone() for t in keep]
         rng = (self.gen.get_state(), self._draw_pos)
-        fused = fused and self.penetration_only == 1
+        fused = fused and self._can_fuse
         fork = fork and not fused
         if fork and self._side is None:
             self._side = torch.cuda.Stream()

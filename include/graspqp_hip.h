@@ -106,6 +106,22 @@ int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, 
                float* g_hand_normals, float* e_fc, float* x_sum, int32_t* n_iter, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* ---- the reference's other force-closure energies (scripts/fit.py:343-347, --energy_type dexgrasp | tdg) -------------
+ * Same inputs as the graspqp energy: contact points, OBJECT normals at the contacts (constants), cog (B,3).  One launch
+ * gives the energy and its gradient w.r.t. the contact points: g_contact_pts (+)= upstream * dE/dp with upstream =
+ * grad_e[row] if grad_e != NULL else w; accumulate = 1 adds to g_contact_pts.  e_fc or g_contact_pts may be NULL.
+ * gq_dexgrasp_energy: metrics/ops/dexgrasp.py:4-34,  E = |sum_i [n_i ; torque_weight (n_i x (p_i - cog))]|^2.
+ * gq_tdg_energy: metrics/ops/tdg.py:147-239 (TDGEnergy.forward behind TDGSpanMetric): directions (P,3) = the force part of
+ *   target_direction_6D (unit vectors; the torque part is zero), friction = miu_coef[0], obb_length = obj_obb_length,
+ *   scale = the factor 100 of TDGSpanMetric.forward.                                                                */
+int gq_dexgrasp_energy(const float* contact_pts, const float* contact_normals, const float* cog, int64_t batch,
+                       int n_contact, float torque_weight, const float* grad_e /* (B) or NULL */, float w, int accumulate,
+                       float* e_fc /* (B) or NULL */, float* g_contact_pts /* (B,n,3) or NULL */, void* stream);
+int gq_tdg_energy(const float* contact_pts, const float* contact_normals, const float* cog, const float* directions,
+                  int n_directions, int64_t batch, int n_contact, float friction, float obb_length, int enable_density,
+                  float scale, const float* grad_e, float w, int accumulate, float* e_fc, float* g_contact_pts,
+                  void* stream);
+
 /* The same step with the hand-penetration branch of the iteration (gq_hand_pen_forward with penetration_only = 1, then
  * gq_hand_pen_backward in its fused-E_pen form) running in the SAME two launches: the two branches are independent
  * until gq_fk_backward, neither fills the GPU on its own at batch 256, and one grid holding both roles overlaps them

@@ -15,5 +15,5 @@ Pinning status (see DESIGN.md "Oracle"):
     restated from the published algorithms: PARITY UNPINNED for those outputs.
 """
 
-from . import export, init, kin, mala, models, qp, sdf, span  # noqa: F401
+from . import export, init, kin, mala, metrics_alt, models, qp, sdf, span  # noqa: F401
 from .energy import calculate_energy, total_energy  # noqa: F401

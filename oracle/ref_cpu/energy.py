@@ -12,17 +12,21 @@ from . import span
 DEFAULT_WEIGHTS = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}  # fit.py:51-55
 
 
-def calculate_energy(hand, obj, svd_gain=0.1, mu=0.2, k=4, max_limit=20.0, box_form=False, fc_solver=None):
-    """-> dict of (B,) tensors E_dis, E_fc, E_joints, E_pen, E_spen, plus '_x' (QP solution sums)."""
+def calculate_energy(hand, obj, svd_gain=0.1, mu=0.2, k=4, max_limit=20.0, box_form=False, fc_solver=None, e_fc_fn=None):
+    """-> dict of (B,) tensors E_dis, E_fc, E_joints, E_pen, E_spen, plus '_x' (QP solution sums).
+    ``e_fc_fn(contact_points, object_normals, cog) -> (B,)`` replaces the graspqp metric (energy types dexgrasp / tdg)."""
     losses = {}
     distance, contact_normal = obj.cal_distance(hand.contact_points)
     nH = hand.contact_normals
     # energy.py:25-28: (1 - sum((-vC) * nH)).exp() * |d|
     losses["E_dis"] = ((1 - ((-contact_normal) * nH).sum(-1)).exp() * distance.abs()).sum(-1)
-    e_fc, xs = span.e_fc(
-        hand.contact_points, contact_normal, obj.cog, svd_gain=svd_gain, mu=mu, k=k, max_limit=max_limit,
-        box_form=box_form, solver=fc_solver,
-    )
+    if e_fc_fn is not None:
+        e_fc, xs = e_fc_fn(hand.contact_points, contact_normal, obj.cog), None
+    else:
+        e_fc, xs = span.e_fc(
+            hand.contact_points, contact_normal, obj.cog, svd_gain=svd_gain, mu=mu, k=k, max_limit=max_limit,
+            box_form=box_form, solver=fc_solver,
+        )
     losses["E_fc"] = e_fc
     th = hand.hand_pose[:, 9:]
     losses["E_joints"] = ((th > hand.joints_upper) * (th - hand.joints_upper)).sum(-1) + (

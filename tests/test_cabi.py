@@ -77,7 +77,10 @@ def test_metric_factory_surface():
     fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
     assert callable(fn)
     with pytest.raises(NotImplementedError):
-        GF.create(GF.MetricType.TDG)
+        GF.create(GF.MetricType.GRASPQP_SCIPY)
+    from graspqp_amd.metrics import DexgraspSpanMetric
+
+    assert isinstance(GF.create(GF.MetricType.DEXGRASP), DexgraspSpanMetric)
     s = SQPLsqSolver.from_mat(torch.zeros(2, 1, 6, 48), torch.zeros(2, 1, 6))
     assert s._batch_size == 2 and s._num_wrenches == 48
 

@@ -277,3 +277,39 @@ def test_oracle_init_pieces_against_scipy_and_torch():
     assert np.abs(((pts.numpy() - hull[f.numpy(), 0]) * nrm[f.numpy()]).sum(1)).max() < 1e-12
     sel = oinit.farthest_points(pts, 20)
     assert sel[0] == 0 and len(set(sel.tolist())) == 20
+
+
+def test_oracle_annealing_dexgraspnet_matches_reference_optimizer(golden_dir):
+    """reference AnnealingDexGraspNet + dexgrasp metric (fixture annealing_*.npz, float32 like the reference's metric)
+    against the oracle's pure functions: same proposal / acceptance arithmetic as MALA* without the z-score."""
+    from ref_cpu import metrics_alt as oalt
+
+    g = np.load(os.path.join(golden_dir, "annealing_dexgrasp_allegro_sphere_b8_n4.npz"), allow_pickle=False)
+    dt = torch.float64
+    hand, obj, be = _scene(g, dt)
+    T = lambda k: torch.tensor(g[k])
+    hp, idx, energy = T("hand_pose0").to(dt), T("contact_idx0"), T("energy0").to(dt)
+    B, D = hp.shape
+    grad, ema = torch.zeros(B, D, dtype=dt), torch.zeros(B, D, dtype=dt)
+    step = torch.full((B,), int(g["step0"]), dtype=torch.long)
+    fc = lambda p, nrm, cog: oalt.dexgrasp_e_fc(p, nrm, cog, 0.0)
+    for s in range(1, int(g["n_steps"]) + 1):
+        p = f"s{s}"
+        hp2, idx2, ema, step, ss = mala.propose(hp, grad, ema, step, idx, T(f"{p}_u_switch"), T(f"{p}_new_idx"))
+        np.testing.assert_allclose(ss.numpy(), g[f"{p}_step_size"], rtol=1e-6)
+        np.testing.assert_allclose(hp2.numpy(), g[f"{p}_prop_pose"], rtol=2e-5, atol=2e-6)
+        assert idx2.tolist() == g[f"{p}_prop_idx"].tolist()
+        hpr = hp2.clone().requires_grad_()
+        hand.set_parameters(hpr, idx2)
+        lo = ref_cpu.calculate_energy(hand, obj, e_fc_fn=fc)
+        np.testing.assert_allclose(lo["E_fc"].detach().numpy(), g[f"{p}_new_E_fc"], rtol=1e-4, atol=1e-5)
+        new_e = ref_cpu.total_energy(lo)
+        new_e.sum().backward()
+        np.testing.assert_allclose(new_e.detach().numpy(), g[f"{p}_new_energy"], rtol=2e-4)
+        acc, Tm = mala.accept(energy, new_e.detach(), step, T(f"{p}_u_accept"), z=None)
+        np.testing.assert_allclose(Tm.numpy(), g[f"{p}_temperature"], rtol=1e-5)
+        assert acc.tolist() == g[f"{p}_accept"].tolist()
+        # teacher forcing (the fixture is float32 arithmetic): continue from the reference's accepted state
+        hp, idx, grad = T(f"{p}_hand_pose").to(dt), T(f"{p}_contact_idx"), T(f"{p}_grad").to(dt)
+        energy, ema = T(f"{p}_energy").to(dt), T(f"{p}_ema").to(dt)
+        assert step.tolist() == g[f"{p}_step"].tolist()

@@ -1,0 +1,177 @@
+"""GPU parity of the reference's other energy types and optimizer (scripts/fit.py:335-347): dexgrasp / tdg force-closure
+energies against fixtures produced by the reference's own metrics/ops/dexgrasp.py and tdg.py (energy 2e-4 rel, gradient
+5e-3 norm-wise: fp32 acos / normalisations), the stepper with those energy types against the oracle composition, and
+AnnealingDexGraspNet against the fixture of the reference class (teacher-forced)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ref_cpu  # noqa: E402
+from ref_cpu import metrics_alt as oalt  # noqa: E402
+from ref_cpu import models as omodels  # noqa: E402
+
+from graspqp_amd.hands import get_hand_spec  # noqa: E402
+from graspqp_amd.utils import meshes  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gq():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from graspqp_amd import _C, ops, stepper
+
+    _C.lib()
+    return type("gq", (), {"ops": ops, "C": _C, "stepper": stepper})
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("n", [4, 12, 20])
+def test_dexgrasp_and_tdg_match_reference_modules(gq, golden_dir, n):
+    from graspqp_amd.metrics import DexgraspSpanMetric, TDGSpanMetric
+
+    g = _load(golden_dir, "alt_metrics.npz")
+    t = f"n{n}"
+    pts, nrm, cog = (torch.tensor(g[f"{t}_{k}"]).cuda() for k in ("contact_pts", "contact_normals", "cog"))
+    dex = DexgraspSpanMetric()
+    for tw in (0, 1, 5):
+        p = pts.clone().requires_grad_()
+        e, ones = dex(p, nrm, cog, torque_weight=float(tw), with_solution=True)
+        assert ones.shape == (pts.shape[0], n) and bool((ones == 1).all())
+        np.testing.assert_allclose(e.detach().cpu().numpy(), g[f"{t}_dex_tw{tw}_e"], rtol=2e-5, atol=1e-6)
+        e.sum().backward()
+        gref = g[f"{t}_dex_tw{tw}_grad"]
+        assert np.linalg.norm(p.grad.cpu().numpy() - gref) <= 1e-4 * np.linalg.norm(gref) + 1e-7
+    m = TDGSpanMetric(device="cuda", directions=g[f"{t}_tdg_directions"])
+    p = pts.clone().requires_grad_()
+    e, none = m(p, nrm, cog)
+    assert none is None
+    np.testing.assert_allclose(e.detach().cpu().numpy(), g[f"{t}_tdg_e"], rtol=2e-4)
+    e.sum().backward()
+    gref = g[f"{t}_tdg_grad"]
+    assert np.linalg.norm(p.grad.cpu().numpy() - gref) <= 5e-3 * np.linalg.norm(gref)
+    # upstream weights and bitwise reproducibility
+    p2 = pts.clone().requires_grad_()
+    w = torch.rand(pts.shape[0], device="cuda")
+    (m(p2, nrm, cog)[0] * w).sum().backward()
+    torch.testing.assert_close(p2.grad, p.grad * w.view(-1, 1, 1), rtol=1e-6, atol=1e-9)
+    assert torch.equal(m(pts, nrm, cog)[0], e.detach())
+
+
+@pytest.mark.parametrize("energy_type", ["dexgrasp", "tdg"])
+def test_stepper_with_other_energy_types(gq, energy_type):
+    """Energy + gradient of the whole composition (E_dis, E_fc of the chosen type, E_pen, E_spen, E_joints) against the
+    fp64 oracle, the class-surface route through GraspSpanMetricFactory, and graph replay == eager."""
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    spec = get_hand_spec("allegro")
+    n_obj, be, n = 2, 6, 12
+    B = n_obj * be
+    fvs = [meshes.superquadric(5 + i, 32, 16) for i in range(n_obj)]
+    sps = [meshes.surface_points(f, 600, oversample=4, seed=3 + i) for i, f in enumerate(fvs)]
+    g0 = torch.Generator().manual_seed(31)
+    t = torch.nn.functional.normalize(torch.randn(B, 3, generator=g0, dtype=torch.float64), dim=-1) * 0.1
+    hp = torch.cat([t, torch.randn(B, 6, generator=g0, dtype=torch.float64),
+                    torch.tensor(spec.default_state, dtype=torch.float64)[None] + 0.3 * torch.randn(B, spec.n_dofs, generator=g0, dtype=torch.float64)], 1)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=g0)
+    dirs = torch.nn.functional.normalize(torch.randn(1000, 3, generator=g0), dim=-1)
+    hand = gq.ops.HandHandle(spec)
+    st = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, energy_type=energy_type,
+                                 tdg_directions=dirs, seed=5)
+    terms, total, grad = st.evaluate(hp.float().cuda(), idx.cuda())
+    torch.cuda.synchronize()
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject(fvs, sps, be, torch.float64)
+    hpo = hp.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    if energy_type == "dexgrasp":
+        fc = lambda p, nrm, cog: oalt.dexgrasp_e_fc(p, nrm, cog, 0.0)
+    else:
+        fc = lambda p, nrm, cog: oalt.tdg_energy(p, nrm, cog, dirs.double())
+    lo = ref_cpu.calculate_energy(oh, oo, e_fc_fn=fc)
+    tot = ref_cpu.total_energy(lo)
+    tot.sum().backward()
+    for k in ("E_dis", "E_fc", "E_pen", "E_spen", "E_joints"):
+        np.testing.assert_allclose(terms[k].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    np.testing.assert_allclose(total.cpu().numpy(), tot.detach().numpy(), rtol=2e-4)
+    go = oh.hand_pose.grad.numpy()
+    assert np.linalg.norm(grad.cpu().numpy() - go) <= 2e-3 * np.linalg.norm(go)
+    # class-surface route with the factory's metric (fit.py:343-347)
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=600)
+    om.initialize_from_meshes(fvs, surface_points_list=sps)
+    hm.set_parameters(hp.float().cuda().requires_grad_(), idx.cuda())
+    fn = GF.create(GF.MetricType.DEXGRASP if energy_type == "dexgrasp" else GF.MetricType.TDG)
+    if energy_type == "tdg":
+        fn.target_direction = dirs.cuda().contiguous()
+    W = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=list(W), svd_gain=0.1)
+    tot2 = sum(W[k] * v for k, v in losses.items())
+    tot2.sum().backward()
+    np.testing.assert_allclose(tot2.detach().cpu().numpy(), total.cpu().numpy(), rtol=2e-5)
+    assert (hm.hand_pose.grad - grad).norm() <= 1e-3 * grad.norm()
+    # iterations: graph replay == eager, finite
+    outs = []
+    for rep in range(2):
+        s2 = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, energy_type=energy_type,
+                                     tdg_directions=dirs, seed=5)
+        s2.reset(hp.float().cuda(), idx.cuda())
+        if rep == 1:
+            s2.capture(iters=2)
+        for _ in range(4):
+            s2.step()
+        s2.flush()
+        torch.cuda.synchronize()
+        outs.append((s2.energy.clone(), s2.hand_pose.clone(), s2.contact_idx.clone()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+def test_annealing_dexgraspnet_matches_reference_optimizer(gq, golden_dir):
+    """GraspStepper(optimizer="dexgraspnet", energy_type="dexgrasp") teacher-forced against the fixture of the reference's
+    AnnealingDexGraspNet + DexgraspSpanMetric run in fit.py order (started at step 61)."""
+    g = _load(golden_dir, "annealing_dexgrasp_allegro_sphere_b8_n4.npz")
+    spec = get_hand_spec("allegro")
+    n_obj, be = int(g["n_obj"]), int(g["batch_size_each"])
+    fvs = [g[f"obj{i}_face_verts"] for i in range(n_obj)]
+    sps = np.stack([g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    st = gq.stepper.GraspStepper(gq.ops.HandHandle(spec), gq.ops.MeshSet(fvs), torch.tensor(sps), be, 4,
+                                 energy_type="dexgrasp", optimizer="dexgraspnet")
+    f32 = lambda k: torch.tensor(g[k], dtype=torch.float32).cuda()
+    st.reset(f32("hand_pose0"), torch.tensor(g["contact_idx0"]).cuda())
+    np.testing.assert_allclose(st.energy.cpu().numpy(), g["energy0"], rtol=3e-4)
+    np.testing.assert_allclose(st.terms[1].cpu().numpy(), g["E_fc0"], rtol=1e-4, atol=1e-5)
+    st.energy.copy_(f32("energy0"))
+    st.step_count.fill_(int(g["step0"]))
+    rel = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - b) / np.maximum(np.abs(b), 1e-12)
+    for s in range(1, int(g["n_steps"]) + 1):
+        p = f"s{s}"
+        if s > 1:
+            q = f"s{s-1}"
+            st.hand_pose.copy_(f32(f"{q}_hand_pose"))
+            st.contact_idx.copy_(torch.tensor(g[f"{q}_contact_idx"]).cuda())
+            st.grad.copy_(f32(f"{q}_grad"))
+            st.energy.copy_(f32(f"{q}_energy"))
+            st.ema.copy_(f32(f"{q}_ema"))
+            st.step_count.copy_(torch.tensor(g[f"{q}_step"]).cuda())
+        st.step(draws=(f32(f"{p}_u_switch"), torch.tensor(g[f"{p}_new_idx"]).cuda(), f32(f"{p}_u_accept")))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(st.s_out.cpu().numpy(), g[f"{p}_step_size"], rtol=1e-5)
+        np.testing.assert_allclose(st.pose_new.cpu().numpy(), g[f"{p}_prop_pose"], rtol=2e-5, atol=3e-6)
+        assert st.idx_new.cpu().tolist() == g[f"{p}_prop_idx"].tolist()
+        np.testing.assert_allclose(st.terms_new[1].cpu().numpy(), g[f"{p}_new_E_fc"], rtol=2e-4, atol=1e-5)
+        assert rel(st.total_new.cpu().numpy(), g[f"{p}_new_energy"]).max() < 5e-4
+        np.testing.assert_allclose(st.temperature.cpu().numpy(), g[f"{p}_temperature"], rtol=1e-4)  # no (1 + Phi(z)) factor
+        assert st.accept.cpu().bool().tolist() == g[f"{p}_accept"].tolist()
+        np.testing.assert_allclose(st.hand_pose.cpu().numpy(), g[f"{p}_hand_pose"], rtol=2e-5, atol=3e-6)
+        assert st.contact_idx.cpu().tolist() == g[f"{p}_contact_idx"].tolist()
+        np.testing.assert_allclose(st.ema.cpu().numpy(), g[f"{p}_ema"], rtol=2e-4, atol=1e-7)
+        assert st.step_count.cpu().tolist() == g[f"{p}_step"].tolist()

@@ -169,3 +169,26 @@ def test_box_form_backward_equals_qpth_block_form():
         v.sum().backward()
         grads.append(Fr.grad)
     assert (grads[0] - grads[1]).abs().max() <= 1e-8 * grads[0].abs().max()
+
+
+@pytest.mark.parametrize("n", [4, 12, 20])
+def test_alt_metrics_oracle_matches_reference_modules(golden_dir, n):
+    """oracle dexgrasp / TDG restatements against the reference's own dexgrasp.py / tdg.py (fixture alt_metrics.npz)."""
+    from ref_cpu import metrics_alt as oalt
+
+    g = _load(golden_dir, "alt_metrics.npz")
+    t = f"n{n}"
+    pts, nrm, cog = (torch.tensor(g[f"{t}_{k}"], dtype=torch.float64) for k in ("contact_pts", "contact_normals", "cog"))
+    for tw in (0, 1, 5):
+        p = pts.clone().requires_grad_()
+        e = oalt.dexgrasp_e_fc(p, nrm, cog, float(tw))
+        np.testing.assert_allclose(e.detach().numpy(), g[f"{t}_dex_tw{tw}_e"], rtol=2e-5, atol=1e-7)
+        if tw:
+            e.sum().backward()
+            np.testing.assert_allclose(p.grad.numpy(), g[f"{t}_dex_tw{tw}_grad"], rtol=2e-4, atol=1e-5)
+    p = pts.clone().requires_grad_()
+    e = oalt.tdg_energy(p, nrm, cog, torch.tensor(g[f"{t}_tdg_directions"], dtype=torch.float64))
+    e.sum().backward()
+    np.testing.assert_allclose(e.detach().numpy(), g[f"{t}_tdg_e"], rtol=2e-4)
+    gref = g[f"{t}_tdg_grad"]
+    assert np.linalg.norm(p.grad.numpy() - gref) <= 2e-3 * np.linalg.norm(gref)

@@ -12,6 +12,8 @@ stores plain input/output tensors:
                    few iterations on the oracle models, with every torch.rand/randint draw recorded
   init_*.npz       reference core/initializations.py::initialize_convex_hull with oracle stand-ins for trimesh /
                    pytorch3d / transforms3d: look_at, pose assembly, truncated-normal joints, env_mask hand-over
+  annealing_*.npz  reference core/optimizer.py::AnnealingDexGraspNet + metrics/ops/dexgrasp.py in fit.py order
+  alt_metrics.npz  reference metrics/ops/dexgrasp.py and tdg.py: energies + contact-point gradients
   mala_ext_*.npz   the same with (R) the step counter started at 149 and a re-initialisation iteration
                    (reset_envs + accept_step(reset_mask)), (C) clip_grad=True and NaN / inf gradient entries
 
@@ -514,6 +516,94 @@ def gen_init():
     print("init: translation norms", pose0[:, :3].norm(dim=1).numpy().round(3).tolist())
 
 
+def gen_alt_metrics():
+    """reference metrics/ops/dexgrasp.py and tdg.py (plain torch, import here): energies and contact-point gradients."""
+    dex = load_ref("_ref_dexgrasp", "metrics/ops/dexgrasp.py")
+    tdg = load_ref("_ref_tdg", "metrics/ops/tdg.py")
+    out = {}
+    for n, B, seed in ((4, 8, 0), (12, 16, 1), (20, 6, 2)):
+        torch.manual_seed(seed)
+        d = torch.nn.functional.normalize(torch.randn(B, n, 3), dim=-1)
+        pts = d * (0.05 + 0.01 * torch.randn(B, n, 1))
+        nrm = torch.nn.functional.normalize(-d + 0.4 * torch.randn(B, n, 3), dim=-1)
+        nrm[0, 0] = torch.tensor([0.0, 1.0, 0.0])  # the |n.y| > 0.99 branch of utils_1axis_to_3axes
+        cog = 0.005 * torch.randn(B, 3)
+        tag = f"n{n}"
+        out.update({f"{tag}_contact_pts": pts, f"{tag}_contact_normals": nrm, f"{tag}_cog": cog})
+        for tw in (0.0, 1.0, 5.0):
+            p = pts.clone().requires_grad_()
+            e, ones = dex.DexgraspSpanMetric()(p, nrm, cog, torque_weight=tw, with_solution=True)
+            (g,) = torch.autograd.grad(e.sum(), p, allow_unused=True)
+            out[f"{tag}_dex_tw{int(tw)}_e"] = e.detach()
+            out[f"{tag}_dex_tw{int(tw)}_grad"] = torch.zeros_like(pts) if g is None else g
+        np.random.seed(100 + seed)
+        m = tdg.TDGSpanMetric(device="cpu")
+        p = pts.clone().requires_grad_()
+        e, _ = m(p, nrm, cog)
+        e.sum().backward()
+        out.update({f"{tag}_tdg_directions": m.tdg_energy.target_direction_6D[0, :, :3], f"{tag}_tdg_e": e.detach(),
+                    f"{tag}_tdg_grad": p.grad})
+        assert float(m.tdg_energy.target_direction_6D[0, :, 3:].abs().max()) == 0.0
+        print(f"alt metrics n={n}: dexgrasp tw=1 {out[f'{tag}_dex_tw1_e'][:2].tolist()} tdg {e[:2].tolist()}")
+    np.savez_compressed(os.path.join(OUT, "alt_metrics.npz"), **to_np(out))
+
+
+def gen_annealing(ref_energy, ref_opt, ref_dex):
+    """reference AnnealingDexGraspNet (core/optimizer.py:11-149) with energy_type dexgrasp (fit.py:337,343-345) in fit.py
+    order, every draw recorded; started at step 61 so that both decay exponents are non-zero."""
+    hand_name, n_obj, be, n, seed, n_steps = "allegro", 2, 4, 4, 29, 3
+    dtype = torch.float32  # the reference's dexgrasp metric is float32-only (dexgrasp.py:19-31)
+    spec, hand, obj, hp, idx, fvs, sps = make_scene(hand_name, n_obj, be, n, dtype, seed, "sphere", n_surface=400)
+    B = n_obj * be
+    hand.set_parameters(hp.clone().requires_grad_(), idx)
+    names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"]
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    fc = ref_dex.DexgraspSpanMetric()
+    opt = ref_opt.AnnealingDexGraspNet(hand, switch_possibility=0.4, starting_temperature=18, temperature_decay=0.95,
+                                       annealing_period=30, step_size=0.005, stepsize_period=50, mu=0.98, device="cpu")
+    losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+    energy = sum(w[k] * v for k, v in losses.items())
+    energy.sum().backward()
+    out = dict(hand_pose0=hand.hand_pose.detach().clone(), contact_idx0=idx.clone(), energy0=energy.detach().clone(),
+               E_fc0=losses["E_fc"].detach().clone(), batch_size_each=be, n_obj=n_obj, n_steps=n_steps, step0=61)
+    opt.zero_grad()
+    opt.step = 61
+    torch.manual_seed(seed)
+    for step in range(1, n_steps + 1):
+        with _Recorder() as rec:
+            s = opt.try_step()
+        u_switch, vals = rec.log[0][1], rec.log[1][1]
+        mask = u_switch < 0.4
+        new_idx = torch.zeros(B, n, dtype=torch.long)
+        new_idx[mask] = vals
+        opt.zero_grad()
+        new_losses = ref_energy.calculate_energy(hand, obj, energy_fnc=fc, energy_names=names, method="gendexgrasp", svd_gain=0.1)
+        new_energy = sum(w[k] * v for k, v in new_losses.items())
+        new_energy.sum().backward()
+        prop_pose = hand.hand_pose.detach().clone()
+        prop_idx = hand.contact_point_indices.clone()
+        with torch.no_grad():
+            with _Recorder() as rec2:
+                accept, T = opt.accept_step(energy, new_energy, None, None, 1.0)
+            energy[accept] = new_energy[accept]
+        out.update({
+            f"s{step}_u_switch": u_switch, f"s{step}_new_idx": new_idx, f"s{step}_u_accept": rec2.log[0][1],
+            f"s{step}_step_size": torch.as_tensor(s).detach().clone().expand(B).clone(), f"s{step}_prop_pose": prop_pose,
+            f"s{step}_prop_idx": prop_idx,
+            f"s{step}_new_energy": new_energy.detach().clone(), f"s{step}_new_E_fc": new_losses["E_fc"].detach().clone(),
+            f"s{step}_accept": accept.clone(), f"s{step}_temperature": torch.as_tensor(T).detach().clone().expand(B).clone(),
+            f"s{step}_hand_pose": hand.hand_pose.detach().clone(), f"s{step}_contact_idx": hand.contact_point_indices.clone(),
+            f"s{step}_grad": hand.hand_pose.grad.detach().clone(), f"s{step}_energy": energy.detach().clone(),
+            f"s{step}_ema": opt.ema_grad_hand_pose.detach().clone().unsqueeze(0).expand(B, -1).clone(),
+            f"s{step}_step": torch.full((B,), int(opt.step), dtype=torch.long),
+        })
+        print(f"annealing step {step}: accept={accept.tolist()}")
+    for i in range(n_obj):
+        out[f"obj{i}_face_verts"] = fvs[i]
+        out[f"obj{i}_surface_points"] = sps[i]
+    np.savez_compressed(os.path.join(OUT, "annealing_dexgrasp_allegro_sphere_b8_n4.npz"), **to_np(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     scipy_solver, registry = ref_metrics()
@@ -525,6 +615,8 @@ def main():
     gen_mala(ref_energy, ref_opt)
     gen_mala_ext(ref_energy, ref_opt)
     gen_init()
+    gen_alt_metrics()
+    gen_annealing(ref_energy, ref_opt, load_ref("_ref_dexgrasp2", "metrics/ops/dexgrasp.py"))
 
 
 if __name__ == "__main__":

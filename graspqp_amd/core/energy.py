@@ -34,7 +34,19 @@ def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[],
     losses["E_pen"] = distances.sum(-1)
     losses["E_spen"] = hand_model.self_penetration()
 
-    for name in ("E_prior", "E_wall", "E_manipulativity"):
-        if name in energy_names:
-            raise NotImplementedError(f"{name} is outside the accelerated hot path (SURVEY 8f-3)")
+    if "E_prior" in energy_names:  # energy.py:68-74: the grasp axis should point down
+        forward_axis = (hand_model.global_rotation @ hand_model.grasp_axis.view(1, -1, 1)).view(-1, 3)
+        axis_prior = torch.tensor([0, 0, -1], dtype=torch.float, device=forward_axis.device).view(1, 3)
+        losses["E_prior"] = 1 - torch.sum(forward_axis * axis_prior, dim=-1)
+
+    if "E_wall" in energy_names:  # energy.py:76-78: hand surface samples below the table plane z = 0
+        z_height = hand_model.get_surface_points()[..., -1].clamp(max=0.0)
+        losses["E_wall"] = z_height.abs().sum(-1)
+
+    if "E_manipulativity" in energy_names:
+        # energy.py:80-87.  Value only: the reference differentiates it through the Jacobian and the pseudo-inverse, but
+        # scripts/fit.py cannot select it (no weight for it: fit.py:363-371 raises on the unknown name), so no backward here
+        E_jacobian = hand_model.get_manipulability(
+            contact_normal * distance.detach().unsqueeze(-1).abs().clamp(min=5e-3), hand_model.contact_point_indices)
+        losses["E_manipulativity"] = E_jacobian.mean(-1)
     return losses

@@ -15,7 +15,7 @@ from ..hands import get_hand_spec
 
 
 class HandModel:
-    def __init__(self, spec, device="cuda", grasp_type=None):
+    def __init__(self, spec, device="cuda", grasp_type=None, n_surface_points=512):
         if not str(device).startswith("cuda"):
             raise RuntimeError("graspqp_amd.HandModel runs on the GPU only (device='cuda'); there is no CPU path")
         self.spec = spec
@@ -42,6 +42,8 @@ class HandModel:
         self.contact_normals = None
         self._sphere_centers = None
         self._fk_ws = None
+        self._n_surface_points = int(n_surface_points)
+        self._surface = None  # (handle whose "candidates" are the hand's surface samples, link-frame points, link ids)
 
     # reference hand_model.py:762-766 -- returns the (B,L,3,4) link transforms (the reference returns a dict of
     # Transform3d keyed by link name; ``link_matrix(name)`` gives the same 4x4 view).
@@ -130,6 +132,63 @@ class HandModel:
         all_idx = torch.arange(self.n_contact_candidates, dtype=torch.long, device=self.device).unsqueeze(0).expand(B, -1)
         _, _, cp, cn, _, _ = ops.fk_contacts(self.hand_pose.detach(), all_idx.contiguous(), self._hand)
         return (cp, cn) if with_normals else cp
+
+    # reference hand_model.py:604-629 + 1042-1071: n_surface_points samples of the hand surface (per link proportional to
+    # its area, 100x oversampled + farthest-point sampling, seed 42) in the world frame.  The reference draws them with
+    # pytorch3d (absent: the sample SET differs, PARITY UNPINNED); here they are produced once on the host and pushed
+    # through the FK kernels as extra "contact candidates", which also gives the analytic backward.
+    def _surface_handle(self):
+        if self._surface is None:
+            import numpy as np
+
+            from ..utils import meshes as mesh_utils
+
+            spec = self.spec
+            fvs = [spec.link_faces(l).astype(np.float64) for l in range(spec.n_links)]
+            areas = [0.5 * np.linalg.norm(np.cross(f[:, 1] - f[:, 0], f[:, 2] - f[:, 0]), axis=1).sum() if len(f) else 0.0 for f in fvs]
+            tot = sum(areas)
+            counts = [int(a / tot * self._n_surface_points) for a in areas]
+            counts[0] += self._n_surface_points - sum(counts)
+            pts, lnk = [], []
+            for l, (f, k) in enumerate(zip(fvs, counts)):
+                if k == 0 or len(f) == 0:
+                    continue
+                dense = mesh_utils.sample_surface(f, 100 * k, seed=42)
+                pts.append(mesh_utils.farthest_point_sampling(dense, k))
+                lnk.append(np.full(k, l, dtype=np.int32))
+            pts, lnk = np.concatenate(pts).astype(np.float32), np.concatenate(lnk)
+            import copy
+
+            s2 = copy.copy(spec)
+            s2.cand_pos, s2.cand_nrm, s2.cand_link = pts, np.tile(np.array([[0, 0, 1.0]], dtype=np.float32), (len(pts), 1)), lnk
+            self._surface = (ops.HandHandle(s2), pts, lnk)
+        return self._surface
+
+    def set_surface_points(self, points, link_ids):
+        """Use the given link-frame samples (Ns,3) / link ids (Ns) instead of drawing them (tests, reproducible runs)."""
+        import copy
+
+        import numpy as np
+
+        s2 = copy.copy(self.spec)
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        s2.cand_pos, s2.cand_link = pts, np.ascontiguousarray(link_ids, dtype=np.int32)
+        s2.cand_nrm = np.tile(np.array([[0, 0, 1.0]], dtype=np.float32), (len(pts), 1))
+        self._surface = (ops.HandHandle(s2), pts, s2.cand_link)
+
+    def get_surface_points(self):
+        """(B, n_surface_points, 3) hand surface samples in the world frame, differentiable w.r.t. hand_pose."""
+        h, pts, _ = self._surface_handle()
+        B = self.hand_pose.shape[0]
+        idx = torch.arange(len(pts), dtype=torch.long, device=self.device).unsqueeze(0).expand(B, -1).contiguous()
+        return ops.fk_contacts(self.hand_pose, idx, h)[2]
+
+    # reference hand_model.py:1073-1077
+    def get_manipulability(self, moving_directions, contact_point_indices=None, coupled=True):
+        _, residuals = self.get_req_joint_velocities(moving_directions, contact_point_indices, coupled=coupled)
+        if not coupled:
+            residuals = residuals.mean(-1)
+        return residuals
 
     # reference hand_model.py:772-777 (HandModel.jacobian -> Chain.jacobian of the pytorch_kinematics fork): geometric
     # Jacobian [J_v; J_w] of every mesh link, hand base frame, at the link-frame origin

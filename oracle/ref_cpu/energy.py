@@ -42,6 +42,14 @@ def calculate_energy(hand, obj, svd_gain=0.1, mu=0.2, k=4, max_limit=20.0, box_f
     return losses
 
 
+def optional_terms(hand):
+    """energy.py:68-78: E_prior = 1 - (R grasp_axis).(0,0,-1); E_wall = sum |min(z, 0)| over the hand's surface samples."""
+    fwd = (hand.global_rotation @ hand.grasp_axis.view(1, -1, 1)).view(-1, 3)
+    e_prior = 1 - (fwd * torch.tensor([0.0, 0.0, -1.0], dtype=fwd.dtype)).sum(-1)
+    e_wall = hand.get_surface_points()[..., -1].clamp(max=0.0).abs().sum(-1)
+    return {"E_prior": e_prior, "E_wall": e_wall}
+
+
 def total_energy(losses, weights=None):
     w = DEFAULT_WEIGHTS if weights is None else weights
     e = 0

@@ -24,6 +24,9 @@ class OracleHand:
         self.joints_upper = torch.as_tensor(spec.joints_upper, dtype=dtype)
         self.default_state = torch.as_tensor(spec.default_state, dtype=dtype)
         self.link_faces = [torch.as_tensor(spec.link_faces(l), dtype=dtype) for l in range(spec.n_links)]
+        self.grasp_axis = torch.as_tensor(spec.grasp_axis, dtype=dtype)
+        self.surface_points = None  # (Ns,3) link-frame samples + self.surface_link (Ns): set by the test / fixture script
+        self.surface_link = None
         self.hand_pose = None
         self.contact_point_indices = None
         self.global_translation = None
@@ -86,6 +89,13 @@ class OracleHand:
             dl = torch.sqrt(d2 + 1e-8) * (-sgn)
             dis.append(dl.reshape(B, N))
         return torch.max(torch.stack(dis, dim=0), dim=0)[0]
+
+    # reference hand_model.py:1042-1071
+    def get_surface_points(self):
+        T = self.current_status[:, torch.as_tensor(self.surface_link, dtype=torch.long)]
+        c = torch.as_tensor(self.surface_points, dtype=self.dtype)
+        ph = (T[..., :3, :3] @ c[None, :, :, None]).squeeze(-1) + T[..., :3, 3]
+        return ph @ self.global_rotation.transpose(1, 2) + self.global_translation.unsqueeze(1)
 
     # reference hand_model.py:989-1040
     def self_penetration(self):

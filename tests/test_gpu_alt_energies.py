@@ -175,3 +175,38 @@ def test_annealing_dexgraspnet_matches_reference_optimizer(gq, golden_dir):
         assert st.contact_idx.cpu().tolist() == g[f"{p}_contact_idx"].tolist()
         np.testing.assert_allclose(st.ema.cpu().numpy(), g[f"{p}_ema"], rtol=2e-4, atol=1e-7)
         assert st.step_count.cpu().tolist() == g[f"{p}_step"].tolist()
+
+
+@pytest.mark.parametrize("tag,n", [("allegro_sphere_b4_n4", 4), ("allegro_sq_b6_n12", 12)])
+def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
+    """E_prior and E_wall (core/energy.py:68-78, selectable with --w_prior / --w_wall) through calculate_energy against
+    the fixture produced by the reference's own energy.py; E_manipulativity is value-only (fit.py cannot select it)."""
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+
+    g = _load(golden_dir, f"energy_{tag}.npz")
+    spec = get_hand_spec("allegro")
+    n_obj, be = int(g["n_obj"]), int(g["batch_size_each"])
+    hm = HandModel(spec, "cuda")
+    hm.set_surface_points(g["opt_surface_points"], g["opt_surface_link"])
+    om = ObjectModel(batch_size_each=be, num_samples=g["obj0_surface_points"].shape[0])
+    om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                              surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+    hp = torch.tensor(g["opt_hand_pose"], dtype=torch.float32).cuda().requires_grad_()
+    hm.set_parameters(hp, torch.tensor(g["contact_idx"]).cuda())
+    fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+    names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints", "E_prior", "E_wall", "E_manipulativity"]
+    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+    np.testing.assert_allclose(losses["E_prior"].detach().cpu().numpy(), g["opt_E_prior"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(losses["E_wall"].detach().cpu().numpy(), g["opt_E_wall"], rtol=1e-5, atol=1e-6)
+    assert losses["E_manipulativity"].shape == (n_obj * be,) and torch.isfinite(losses["E_manipulativity"]).all()
+    (2.0 * losses["E_prior"] + 3.0 * losses["E_wall"]).sum().backward()
+    gref = g["opt_grad"]
+    assert np.linalg.norm(hm.hand_pose.grad.cpu().numpy() - gref) <= 1e-4 * np.linalg.norm(gref)
+    # the default hand surface samples: n_surface_points of them, on the link meshes, spread over the links by area
+    hm2 = HandModel(spec, "cuda")
+    hm2.set_parameters(hp.detach(), torch.tensor(g["contact_idx"]).cuda())
+    sp = hm2.get_surface_points()
+    assert sp.shape == (n_obj * be, 512, 3) and torch.isfinite(sp).all()

@@ -192,3 +192,19 @@ def test_alt_metrics_oracle_matches_reference_modules(golden_dir, n):
     np.testing.assert_allclose(e.detach().numpy(), g[f"{t}_tdg_e"], rtol=2e-4)
     gref = g[f"{t}_tdg_grad"]
     assert np.linalg.norm(p.grad.numpy() - gref) <= 2e-3 * np.linalg.norm(gref)
+
+
+@pytest.mark.parametrize("tag", ["allegro_sphere_b4_n4", "allegro_sq_b6_n12"])
+def test_optional_energy_terms_match_reference(golden_dir, tag):
+    """E_prior / E_wall of reference core/energy.py:68-78 (run on the oracle hand with seeded surface samples)."""
+    g = _load(golden_dir, f"energy_{tag}.npz")
+    spec, hand, obj = _scene(g, "allegro", torch.float64)
+    hand.surface_points, hand.surface_link = g["opt_surface_points"], g["opt_surface_link"]
+    hp = torch.tensor(g["opt_hand_pose"], dtype=torch.float64, requires_grad=True)
+    hand.set_parameters(hp, torch.tensor(g["contact_idx"]))
+    o = ref_cpu.energy.optional_terms(hand)
+    np.testing.assert_allclose(o["E_prior"].detach().numpy(), g["opt_E_prior"], rtol=1e-10)
+    np.testing.assert_allclose(o["E_wall"].detach().numpy(), g["opt_E_wall"], rtol=1e-10)
+    assert (g["opt_E_wall"] > 0).any()
+    (2.0 * o["E_prior"] + 3.0 * o["E_wall"]).sum().backward()
+    np.testing.assert_allclose(hand.hand_pose.grad.numpy(), g["opt_grad"], rtol=1e-8, atol=1e-10)

@@ -177,6 +177,22 @@ def gen_energy(ref_energy):
         tot.sum().backward()
         out = dict(hand_pose=hp, contact_idx=idx, total=tot, grad=hand.hand_pose.grad,
                    batch_size_each=be, n_obj=n_obj)
+        # the optional terms of energy.py:68-78 (E_prior, E_wall) from the same reference file, on seeded surface samples
+        rng = np.random.default_rng(5)
+        sl = np.sort(rng.integers(0, spec.n_links, 64)).astype(np.int32)
+        spts = np.stack([spec.link_faces(int(l))[rng.integers(0, len(spec.link_faces(int(l))))].mean(0) for l in sl]).astype(np.float64)
+        hand.surface_points, hand.surface_link = spts, sl
+        hp2 = hp.detach().clone()
+        hp2[:, 2] -= 0.08  # part of the hand below the table plane z = 0
+        hp2.requires_grad_()
+        hand.set_parameters(hp2, idx)
+        opt_l = ref_energy.calculate_energy(
+            hand, obj, energy_fnc=_FcAdapter(mu=0.2, k=4, max_limit=20.0),
+            energy_names=["E_dis", "E_fc", "E_pen", "E_spen", "E_joints", "E_prior", "E_wall"], method="gendexgrasp", svd_gain=0.1)
+        (2.0 * opt_l["E_prior"] + 3.0 * opt_l["E_wall"]).sum().backward()
+        out.update(opt_hand_pose=hp2, opt_surface_points=spts, opt_surface_link=sl, opt_E_prior=opt_l["E_prior"],
+                   opt_E_wall=opt_l["E_wall"], opt_grad=hand.hand_pose.grad)
+        hand.set_parameters(hp, idx)
         for k, v in losses.items():
             out[k] = v
         for i in range(n_obj):

@@ -68,6 +68,9 @@ class HandDesc(ctypes.Structure):
         ("sphere_link", ctypes.c_void_p),
         ("joints_lower", ctypes.c_void_p),
         ("joints_upper", ctypes.c_void_p),
+        ("n_actuated", ctypes.c_int32),
+        ("coupling", ctypes.c_void_p),
+        ("coupling_offset", ctypes.c_void_p),
     ]
 
 

@@ -25,7 +25,10 @@ class HandModel:
         self.n_contact_candidates = spec.n_contact_candidates
         self._actuated_joints_names = list(spec.joint_names)
         self.joints_names = list(spec.joint_names)
-        self._contact_links = None  # reference hand_model.py:451: the grasp_type's link subset, None for the default type
+        # reference hand_model.py:451: the grasp_type's link subset (a spec from get_hand_spec(..., grasp_type=...) carries
+        # it), None for the default type
+        self._contact_links = getattr(spec, "contact_links", None)
+        self.grasp_type = getattr(spec, "grasp_type", grasp_type)
         self.joints_lower = torch.tensor(spec.joints_lower, device=self.device)
         self.joints_upper = torch.tensor(spec.joints_upper, device=self.device)
         self.default_state = torch.tensor(spec.default_state, device=self.device)
@@ -237,6 +240,6 @@ class HandModel:
         return self.n_dofs
 
 
-def get_hand_model(hand_name: str, device="cuda", asset_dir=None, **kwargs) -> HandModel:
-    """reference hands/__init__.py:27-28"""
-    return HandModel(get_hand_spec(hand_name, asset_dir), device=device, **kwargs)
+def get_hand_model(hand_name: str, device="cuda", asset_dir=None, grasp_type=None, **kwargs) -> HandModel:
+    """reference hands/__init__.py:27-28 (``grasp_type`` as in scripts/fit.py:304)"""
+    return HandModel(get_hand_spec(hand_name, asset_dir, grasp_type=grasp_type), device=device, grasp_type=grasp_type, **kwargs)

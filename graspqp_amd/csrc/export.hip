@@ -31,6 +31,7 @@ struct GqJacArgs {
 template <bool LINKS>
 __global__ __launch_bounds__(GQ_WAVE) void gq_jacobian_kernel(GqJacArgs g) {
   __shared__ int s_parent[GQ_WAVE];
+  __shared__ float s_col[GQ_WAVE * 6];  // coupled hands: tree-joint columns, folded into actuated columns (J_act = J_tree C)
   const gqHand& h = g.h;
   const int row = blockIdx.x, lane = gq_lane();
   gq3 a = gq_mk(0, 0, 0), p = gq_mk(0, 0, 0);
@@ -68,14 +69,30 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_jacobian_kernel(GqJacArgs g) {
         jv = a;
       }
     }
-    if (lane < h.J) {
+    if (h.coup) {  // the reference's jacobian_fnc (hands/ability_hand.py:33-40, panda.py:17-26): columns combined by C
+      gq_wave_sync();
+      s_col[lane * 6 + 0] = jv.x; s_col[lane * 6 + 1] = jv.y; s_col[lane * 6 + 2] = jv.z;
+      s_col[lane * 6 + 3] = jw.x; s_col[lane * 6 + 4] = jw.y; s_col[lane * 6 + 5] = jw.z;
+      gq_wave_sync();
+      float v[6] = {0, 0, 0, 0, 0, 0};
+      if (lane < h.JA)
+        for (int j = 0; j < h.J; ++j) {
+          const float cj = h.coup[j * h.JA + lane];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] = fmaf(cj, s_col[j * 6 + k], v[k]);
+        }
+      jv = gq_mk(v[0], v[1], v[2]);
+      jw = gq_mk(v[3], v[4], v[5]);
+    }
+    if (lane < h.JA) {
+      const int JA = h.JA;
       if (LINKS) {
-        float* o = g.out + (((size_t)row * h.L + c) * 6) * h.J + lane;
-        o[0] = jv.x; o[h.J] = jv.y; o[2 * h.J] = jv.z;
-        o[3 * h.J] = jw.x; o[4 * h.J] = jw.y; o[5 * h.J] = jw.z;
+        float* o = g.out + (((size_t)row * h.L + c) * 6) * JA + lane;
+        o[0] = jv.x; o[JA] = jv.y; o[2 * JA] = jv.z;
+        o[3 * JA] = jw.x; o[4 * JA] = jw.y; o[5 * JA] = jw.z;
       } else {
-        float* o = g.out + (((size_t)row * g.n + c) * 3) * h.J + lane;
-        o[0] = jv.x; o[h.J] = jv.y; o[2 * h.J] = jv.z;
+        float* o = g.out + (((size_t)row * g.n + c) * 3) * JA + lane;
+        o[0] = jv.x; o[JA] = jv.y; o[2 * JA] = jv.z;
       }
     }
   }

@@ -80,7 +80,14 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
   const gq3 tg = gq_mk(hp[0], hp[1], hp[2]);
   GqT A = gq_t_identity();
   if (lane < h.J) {
-    A = gq_t_mul(pre, gq_joint_motion(ntype, ax, hp[9 + lane]));
+    float q;
+    if (h.coup) {  // coupled hand: theta_tree = C theta_act + c0 (hands/ability_hand.py:9-26, panda.py:6-14)
+      q = h.coup0[lane];
+      for (int a = 0; a < h.JA; ++a) q = fmaf(h.coup[lane * h.JA + a], hp[9 + a], q);
+    } else {
+      q = hp[9 + lane];
+    }
+    A = gq_t_mul(pre, gq_joint_motion(ntype, ax, q));
     if (parent < 0) gq_t_store(sW + lane * 12, A);
   }
   gq_wave_sync();
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
       en_on = gq_mk(g.en.obj_dir[t * 3], g.en.obj_dir[t * 3 + 1], g.en.obj_dir[t * 3 + 2]);
       en_nh = gq_mk(g.en.hand_normals[t * 3], g.en.hand_normals[t * 3 + 1], g.en.hand_normals[t * 3 + 2]);
     }
-    if (lane < h.J) {
+    if (lane < h.JA) {
       en_jhi = g.en.joints_upper[lane];
       en_jlo = g.en.joints_lower[lane];
       en_th = hp[9 + lane];
@@ -359,12 +366,23 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fk_backward_kernel(GqFkBwdArgs g) 
   }
   float* go = g.grad_pose + (size_t)row * g.D;
   float ej = 0.0f;
+  float gth = 0.0f;
   if (lane < h.J) {  // d E / d theta_j = axis_w . (m - o x f)  (revolute) | axis_w . f (prismatic)
     const gq3 f = gq_mk(nf[0], nf[1], nf[2]), m = gq_mk(nf[3], nf[4], nf[5]);
     const gq3 aw = gq_t_rot(Wj, axj);
     const gq3 o = gq_t_pos(Wj);
-    float gth = (ntype == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
-    if (g.g_theta) gth += g.g_theta[(size_t)row * h.J + lane];
+    gth = (ntype == 1) ? gq_dot(aw, m - gq_cross(o, f)) : gq_dot(aw, f);
+  }
+  if (h.coup) {  // coupled hand: d / d theta_act = C' (d / d theta_tree)  (the jacobian_fnc of the reference's hand files)
+    __syncthreads();
+    if (lane < h.J) sNF[lane] = gth;
+    __syncthreads();
+    gth = 0.0f;
+    if (lane < h.JA)
+      for (int j = 0; j < h.J; ++j) gth = fmaf(h.coup[j * h.JA + lane], sNF[j], gth);
+  }
+  if (lane < h.JA) {
+    if (g.g_theta) gth += g.g_theta[(size_t)row * h.JA + lane];
     if (g.en.total) {  // E_joints = sum relu(theta - hi) + relu(lo - theta)  (energy.py:47-54)
       const float th = en_th, hi = en_jhi, lo = en_jlo;
       if (th > hi) {
@@ -550,8 +568,13 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
     GQ_REQUIRE(d->sphere_link[s] >= 0 && d->sphere_link[s] < d->n_links, "hand_create: sphere_link out of range");
     GQ_REQUIRE(s == 0 || d->sphere_link[s] >= d->sphere_link[s - 1], "hand_create: sphere_link must be sorted");
   }
+  const int JA = (d->n_actuated > 0 && d->coupling) ? d->n_actuated : d->n_dofs;
+  GQ_REQUIRE(JA > 0 && JA <= 64 && (d->n_actuated <= 0 || d->coupling), "hand_create: n_actuated without a coupling matrix");
   gqHand* h = new gqHand();
   h->J = d->n_dofs;
+  h->JA = JA;
+  h->coup = nullptr;
+  h->coup0 = nullptr;
   h->L = d->n_links;
   h->C = d->n_cand;
   h->S = d->n_spheres;
@@ -573,8 +596,13 @@ int gq_hand_create(const gqHandDesc* d, gqHand** out) {
   rc |= gq_upload(&h->cand_link, d->cand_link, h->C);
   rc |= gq_upload(&h->sphere, d->sphere, (size_t)h->S * 4);
   rc |= gq_upload(&h->sphere_link, d->sphere_link, h->S);
-  rc |= gq_upload(&h->jlo, d->joints_lower, h->J);
-  rc |= gq_upload(&h->jhi, d->joints_upper, h->J);
+  rc |= gq_upload(&h->jlo, d->joints_lower, h->JA);
+  rc |= gq_upload(&h->jhi, d->joints_upper, h->JA);
+  if (d->n_actuated > 0 && d->coupling) {
+    float zero[64] = {0};
+    rc |= gq_upload(&h->coup, d->coupling, (size_t)h->J * h->JA);
+    rc |= gq_upload(&h->coup0, d->coupling_offset ? d->coupling_offset : (const float*)zero, (size_t)h->J);
+  }
   rc |= gq_upload(&h->group_off, (const int32_t*)groups, (size_t)ng + 1);
   {
     int32_t grp[256];
@@ -613,7 +641,7 @@ int gq_hand_destroy(gqHand* h) {
   if (!h) return GQ_OK;
   void* p[] = {h->node_parent, h->node_type, h->node_pre, h->node_axis, h->link_node, h->link_offset, h->cand_pos,
                h->cand_nrm, h->cand_link, h->sphere, h->sphere_link, h->jlo, h->jhi, h->group_off, h->node_depth,
-               h->child_off, h->child_idx, h->sphere_grp};
+               h->child_off, h->child_idx, h->sphere_grp, h->coup, h->coup0};
   for (void* q : p)
     if (q) (void)hipFree(q);
   delete h;
@@ -643,7 +671,7 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
   a.idx = contact_idx;
   a.B = (int)batch;
   a.n = n_contact;
-  a.D = 9 + h->J;
+  a.D = 9 + h->JA;
   a.Rg = Rg;
   a.link_T = link_T;
   a.node_W = (float*)workspace;
@@ -736,7 +764,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
   a.g_R = g_R;
   a.B = (int)batch;
   a.n = (g_contact_points || g_contact_normals) ? n_contact : 0;
-  a.D = 9 + h->J;
+  a.D = 9 + h->JA;
   a.node_F = (float*)workspace + (size_t)batch * h->J * 12;
   a.grad_pose = grad_pose;
   if (energy) a.en = *energy;
@@ -756,7 +784,7 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
     a.ac.idx_new = contact_idx;
     a.ac.grad_new = grad_pose;
     a.ac.B = (int)batch;
-    a.ac.D = 9 + h->J;
+    a.ac.D = 9 + h->JA;
     a.ac.n = n_contact;
     a.ac.T0 = c.starting_temperature;
     a.ac.decay = c.decay;

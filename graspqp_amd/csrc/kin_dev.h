@@ -5,7 +5,9 @@
 #include "wave.h"
 
 struct gqHand {
-  int J, L, C, S, NG, max_depth;
+  int J, L, C, S, NG, max_depth;  // J = moving joints of the tree (nodes)
+  int JA;                         // actuated joints = pose dimension - 9 (== J unless the hand is coupled)
+  float *coup, *coup0;            // (J,JA), (J): theta_tree = coup theta_act + coup0; null = identity
   int32_t *node_parent, *node_type, *link_node, *cand_link, *sphere_link, *group_off;
   int32_t *node_depth, *child_off, *child_idx;  // tree levels and per-node child lists (wave-parallel FK)
   int32_t* sphere_grp;                          // (S) group (= link run) of every penetration sphere

@@ -103,10 +103,18 @@ class HandSpec:
     frame_dof: np.ndarray = None  # (F,) int32 index into joint angles, -1 if fixed
     frame_origin: np.ndarray = None  # (F,4,4) float32 joint origin (parent link frame -> joint frame)
     frame_axis: np.ndarray = None  # (F,3) float32 unit axis in joint frame
-    joint_names: List[str] = field(default_factory=list)  # actuated joints, DFS order
-    joints_lower: np.ndarray = None  # (J,)
+    joint_names: List[str] = field(default_factory=list)  # ACTUATED joints, DFS order (reference _actuated_joints_names)
+    joints_lower: np.ndarray = None  # (J,)  J = number of actuated joints = pose dimension - 9
     joints_upper: np.ndarray = None  # (J,)
     default_state: np.ndarray = None  # (J,)
+    # coupled hands (reference hands/{ability_hand,panda,schunk}.py: joint_filter + joint_calc_fnc / jacobian_fnc): the
+    # kinematic tree has N >= J moving joints, theta_full = coupling @ theta_actuated + coupling_offset.  For the other
+    # hands N == J and coupling is the identity.
+    full_joint_names: List[str] = field(default_factory=list)  # all moving joints of the tree, DFS order (N)
+    coupling: np.ndarray = None  # (N,J) float32
+    coupling_offset: np.ndarray = None  # (N,) float32
+    # grasp-type link subsets (reference <hand>/eigengrasps.json, hand_model.py:438-451): JSON text, "" if the hand has none
+    eigengrasps: str = ""
     # ---- mesh links ----------------------------------------------------------------------------
     link_names: List[str] = field(default_factory=list)  # mesh links, DFS order (reference self.mesh)
     link_frame: np.ndarray = None  # (L,) int32 frame index
@@ -119,11 +127,11 @@ class HandSpec:
     # ---- penetration spheres ---------------------------------------------------------------------
     sphere: np.ndarray = None  # (S,4) xyz r, link frame
     sphere_link: np.ndarray = None  # (S,) int32 mesh-link index (non-decreasing)
-    # ---- reduced tree for kernels: one node per actuated joint -------------------------------------
-    node_parent: np.ndarray = None  # (J,) int32 parent node (-1 = hand base)
-    node_pre: np.ndarray = None  # (J,4,4) float32 fixed transform parent-node frame -> this joint frame
-    node_axis: np.ndarray = None  # (J,3)
-    node_type: np.ndarray = None  # (J,) int32 (REVOLUTE / PRISMATIC)
+    # ---- reduced tree for kernels: one node per moving joint of the tree (N) ---------------------------
+    node_parent: np.ndarray = None  # (N,) int32 parent node (-1 = hand base)
+    node_pre: np.ndarray = None  # (N,4,4) float32 fixed transform parent-node frame -> this joint frame
+    node_axis: np.ndarray = None  # (N,3)
+    node_type: np.ndarray = None  # (N,) int32 (REVOLUTE / PRISMATIC)
     link_node: np.ndarray = None  # (L,) int32 node the mesh link rides on (-1 = base)
     link_offset: np.ndarray = None  # (L,4,4) float32 constant transform node frame -> link frame
     # ---- axes used by initialisation ----------------------------------------------------------------
@@ -137,6 +145,24 @@ class HandSpec:
         return len(self.joint_names)
 
     @property
+    def n_nodes(self) -> int:
+        return len(self.full_joint_names)
+
+    @property
+    def is_coupled(self) -> bool:
+        return self.n_nodes != self.n_dofs or not np.array_equal(self.coupling, np.eye(self.n_dofs, dtype=np.float32)) \
+            or bool(np.any(self.coupling_offset != 0))
+
+    def full_joint_angles(self, theta):
+        """theta (..., J) actuated -> (..., N) angles of every moving joint (numpy or torch)."""
+        if hasattr(theta, "detach"):
+            import torch
+
+            C = torch.as_tensor(self.coupling, dtype=theta.dtype, device=theta.device)
+            return theta @ C.T + torch.as_tensor(self.coupling_offset, dtype=theta.dtype, device=theta.device)
+        return np.asarray(theta) @ self.coupling.T + self.coupling_offset
+
+    @property
     def n_links(self) -> int:
         return len(self.link_names)
 
@@ -147,6 +173,53 @@ class HandSpec:
     @property
     def n_spheres(self) -> int:
         return int(self.sphere.shape[0])
+
+    def grasp_types(self) -> List[str]:
+        return sorted(json.loads(self.eigengrasps)) if self.eigengrasps else []
+
+    def with_grasp_type(self, grasp_type: str) -> "HandSpec":
+        """The hand restricted to a grasp type of its eigengrasps.json (reference hand_model.py:438-451,262-263,278-279):
+        contact candidates only on the listed links, ``n_points`` of them per link, and the default joint state of the
+        unused fingers moved to the upper limit for "pinch" / "precision" (hand_model.py:550-589).  The reference samples
+        the candidates of a link by farthest-point sampling from a fixed seed, so the n_points candidates of a link are
+        the first n_points of its default set (farthest-point sequences are nested); a request for MORE points than the
+        dumped set holds cannot be honoured (no trimesh here) and raises."""
+        import copy
+
+        if not self.eigengrasps:
+            raise ValueError(f"{self.name}: no eigengrasps.json for this hand")
+        data = json.loads(self.eigengrasps)
+        if grasp_type not in data:
+            raise ValueError(f"grasp type {grasp_type} not found in eigengrasps.json. Available grasp types are {list(data.keys())}")
+        links = data[grasp_type]
+        keep = []
+        for li, lname in enumerate(self.link_names):
+            idx = np.nonzero(self.cand_link == li)[0]
+            if lname not in links or len(idx) == 0:
+                continue
+            k = int(links[lname].get("n_points", len(idx))) if isinstance(links[lname], dict) else len(idx)
+            if k > len(idx):
+                raise NotImplementedError(f"{self.name}/{grasp_type}: {k} contact candidates requested on {lname}, the "
+                                          f"reference's dump holds {len(idx)}")
+            keep.append(idx[:k])
+        s = copy.copy(self)
+        keep = np.concatenate(keep) if keep else np.zeros(0, dtype=np.int64)
+        s.cand_pos, s.cand_nrm, s.cand_link = self.cand_pos[keep], self.cand_nrm[keep], self.cand_link[keep]
+        s.contact_links = links
+        ds = self.default_state.copy()
+        rules = {  # hand_model.py:550-589: (substrings of the fingers to fold away, joint-name parts that are left alone)
+            ("allegro", "pinch"): (("middle", "ring"), ("joint_0",)), ("allegro", "precision"): (("ring",), ("joint_0",)),
+            ("shadow_hand", "pinch"): (("MF", "RF", "LF"), ("J3", "LFJ4")), ("shadow_hand", "precision"): (("RF", "LF"), ("J3", "LFJ4")),
+            ("ability_hand", "pinch"): (("middle", "ring", "pinky"), ()), ("ability_hand", "precision"): (("ring", "pinky"), ()),
+        }
+        r = rules.get((self.name, grasp_type))
+        if r is not None:
+            for i, jn in enumerate(self.joint_names):
+                if any(f in jn for f in r[0]) and not any(x in jn for x in r[1]):
+                    ds[i] = self.joints_upper[i]
+        s.default_state = ds
+        s.grasp_type = grasp_type
+        return s
 
     def link_faces(self, l: int) -> np.ndarray:
         return self.face_verts[self.link_face_offset[l] : self.link_face_offset[l + 1]]
@@ -169,9 +242,9 @@ class HandSpec:
         kw = {}
         for f in fields(cls):
             v = z[f.name]
-            if f.name in ("frame_names", "joint_names", "link_names"):
+            if f.name in ("frame_names", "joint_names", "link_names", "full_joint_names"):
                 kw[f.name] = [str(s) for s in v.tolist()]
-            elif f.name == "name":
+            elif f.name in ("name", "eigengrasps"):
                 kw[f.name] = str(v)
             else:
                 kw[f.name] = v
@@ -200,6 +273,9 @@ def build_hand_spec(
     grasp_axis: Optional[str] = None,
     use_collision_if_possible: bool = True,
     only_use_collision: bool = False,
+    joint_filter: Optional[List[str]] = None,
+    coupling: Optional[Dict[str, tuple]] = None,
+    eigengrasps_path: Optional[str] = None,
 ) -> HandSpec:
     """URDF + OBJ meshes + JSON side files -> HandSpec (reference hand_model.py:395-696)."""
     root = ET.parse(urdf_path).getroot()
@@ -342,7 +418,26 @@ def build_hand_spec(
             frame_node[f] = d
             frame_off[f] = np.eye(4)
 
-    ds = np.zeros(J) if default_state is None else np.asarray(default_state, dtype=np.float64)
+    # ---- actuated joints and coupling (reference joint_filter / _joint_mask, hand_model.py:472-478,546-548;
+    # joint_calc_fnc of hands/{ability_hand,panda,schunk}.py): theta_full = C theta_act + c0
+    full_joint_names = list(joint_names)
+    act = [n for n in full_joint_names if joint_filter is None or n in joint_filter]
+    C = np.zeros((J, len(act)))
+    c0 = np.zeros(J)
+    for jn_i, jn in enumerate(full_joint_names):
+        if coupling is not None and jn in coupling:
+            src, mult, off = coupling[jn]
+            C[jn_i, act.index(src)] = mult
+            c0[jn_i] = off
+        elif jn in act:
+            C[jn_i, act.index(jn)] = 1.0
+        else:
+            raise ValueError(f"{name}: joint {jn} is neither actuated nor coupled to an actuated joint")
+    mask = [full_joint_names.index(n) for n in act]
+    lo, hi = [lo[i] for i in mask], [hi[i] for i in mask]
+    joint_names = act
+    ds = np.zeros(len(act)) if default_state is None else np.asarray(default_state, dtype=np.float64)
+    eig = open(eigengrasps_path).read() if eigengrasps_path and os.path.exists(eigengrasps_path) else ""
     f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
     i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32))
     spec = HandSpec(
@@ -357,6 +452,10 @@ def build_hand_spec(
         joints_lower=f32(lo),
         joints_upper=f32(hi),
         default_state=f32(ds),
+        full_joint_names=full_joint_names,
+        coupling=f32(C),
+        coupling_offset=f32(c0),
+        eigengrasps=eig,
         link_names=link_names,
         link_frame=i32(link_frame),
         link_face_offset=i32(face_off),

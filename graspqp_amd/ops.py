@@ -493,7 +493,7 @@ class HandHandle:
             return a.ctypes.data_as(ctypes.c_void_p)
 
         d = _C.HandDesc()
-        d.n_dofs, d.n_links = spec.n_dofs, spec.n_links
+        d.n_dofs, d.n_links = spec.n_nodes, spec.n_links  # tree joints; the pose carries spec.n_dofs actuated ones
         d.n_cand, d.n_spheres = spec.n_contact_candidates, spec.n_spheres
         d.node_parent = arr(spec.node_parent, np.int32)
         d.node_type = arr(spec.node_type, np.int32)
@@ -508,6 +508,10 @@ class HandHandle:
         d.sphere_link = arr(spec.sphere_link, np.int32)
         d.joints_lower = arr(spec.joints_lower, np.float32)
         d.joints_upper = arr(spec.joints_upper, np.float32)
+        if spec.is_coupled:  # theta_tree = coupling theta_actuated + offset (ability_hand, panda)
+            d.n_actuated = spec.n_dofs
+            d.coupling = arr(spec.coupling, np.float32)
+            d.coupling_offset = arr(spec.coupling_offset, np.float32)
         h = ctypes.c_void_p(0)
         _C.call("gq_hand_create", ctypes.byref(d), ctypes.byref(h))
         self.handle = h

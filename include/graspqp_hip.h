@@ -151,7 +151,8 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
 /* ---- hand kinematics: HandModel.set_parameters / fk / _set_contact_idxs -----------------------------
  * reference: core/hand_model.py:762-766,787-873,1220-1267  utils/transforms.py:5-13
  * The hand is described by a reduced kinematic tree (fixed joints folded, see graspqp_amd/hands/spec.py).
- * hand_pose (B, 9 + n_dofs) = [t(3), rot6d(6), theta]; transforms are 3x4 row-major [R|t].                 */
+ * hand_pose (B, 9 + JA) = [t(3), rot6d(6), theta_actuated]; transforms are 3x4 row-major [R|t].  JA = number of
+ * actuated joints (= n_dofs unless the hand is coupled, see gqHandDesc.n_actuated).                              */
 typedef struct gqHandDesc { /* all pointers HOST */
   int32_t n_dofs, n_links, n_cand, n_spheres;
   const int32_t* node_parent; /* (J) parent node, -1 = base; parents precede children */
@@ -165,8 +166,14 @@ typedef struct gqHandDesc { /* all pointers HOST */
   const int32_t* cand_link;   /* (C) */
   const float* sphere;        /* (S,4) penetration spheres x y z r, link frame */
   const int32_t* sphere_link; /* (S) non-decreasing */
-  const float* joints_lower;  /* (J) */
-  const float* joints_upper;  /* (J) */
+  const float* joints_lower;  /* (JA) limits of the ACTUATED joints (JA = n_actuated, or J when n_actuated = 0) */
+  const float* joints_upper;  /* (JA) */
+  /* coupled hands (reference hands/{ability_hand,panda,schunk}.py: joint_filter + joint_calc_fnc / jacobian_fnc): the pose
+   * carries n_actuated joint values, the J tree joints follow theta_tree = coupling theta_actuated + coupling_offset.
+   * n_actuated = 0 (or coupling = NULL): every tree joint is actuated, pose dimension 9 + J.                        */
+  int32_t n_actuated;
+  const float* coupling;        /* (J, n_actuated) row-major, host, or NULL */
+  const float* coupling_offset; /* (J) host, or NULL */
 } gqHandDesc;
 typedef struct gqHand gqHand;
 int gq_hand_create(const gqHandDesc* desc, gqHand** out);
@@ -241,17 +248,18 @@ int gq_fk_backward(const gqHand* h, const float* hand_pose, const int64_t* conta
  * Explicit geometric Jacobians in the hand frame.  `workspace` is the FK workspace written by gq_fk_forward for the
  * same poses (it holds the per-joint frames), link_T the link transforms of that call.
  * gq_link_jacobian: HandModel.jacobian (core/hand_model.py:772-777 -> the pytorch_kinematics fork's tree
- *   Chain.jacobian): (B,L,6,J) = [J_v ; J_w] of every mesh link at its frame origin.
+ *   Chain.jacobian, or the hand's jacobian_fnc for coupled hands): (B,L,6,JA) = [J_v ; J_w] of every mesh link at its
+ *   frame origin, columns = actuated joints.
  * gq_contact_jacobian: the linear contact Jacobian J_v + J_w x r of hand_model.py:1176-1196, (B,n,3,J).
  * gq_joint_velocities: HandModel.get_req_joint_velocities (hand_model.py:1155-1218, coupled form): theta =
  *   pinv(J) d with the damped pseudo-inverse of hand_model.py:46-54 (lambda = 1e-3 there), J (B,m,n_dofs) with m = 3 n,
  *   directions (B,m) in the WORLD frame when Rg is given (they are rotated into the hand frame, :1166) else in the hand
  *   frame; residual (B,m) = (J theta - d)^2, ee_vel (B,m) = J theta rotated back to the world frame.  n_dofs <= 64.
  * gq_root_pose_wxyz: (B,7) = [t, unit quaternion w x y z] of hand_pose[:, :9] (fit.py:260-263).                    */
-int gq_link_jacobian(const gqHand* h, int64_t batch, const float* link_T /* (B,L,12) */, float* jac /* (B,L,6,J) */,
+int gq_link_jacobian(const gqHand* h, int64_t batch, const float* link_T /* (B,L,12) */, float* jac /* (B,L,6,JA) */,
                      const void* workspace, size_t workspace_bytes, void* stream);
 int gq_contact_jacobian(const gqHand* h, const int64_t* contact_idx /* (B,n) */, int64_t batch, int n_contact,
-                        const float* link_T, float* jac /* (B,n,3,J) */, const void* workspace, size_t workspace_bytes,
+                        const float* link_T, float* jac /* (B,n,3,JA) */, const void* workspace, size_t workspace_bytes,
                         void* stream);
 int gq_joint_velocities(const float* jac, const float* directions, const float* Rg /* (B,9) or NULL */, int64_t batch,
                         int m, int n_dofs, float damping, float* theta /* (B,n_dofs) */, float* residual /* or NULL */,

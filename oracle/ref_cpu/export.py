@@ -27,6 +27,7 @@ def pinv(A: torch.Tensor, l: float = 1e-3) -> torch.Tensor:
 def _frame_worlds(spec, theta):
     """World (hand-base) transform of every URDF frame, list of (B,4,4) (same walk as kin.forward_kinematics)."""
     B, dt = theta.shape[0], theta.dtype
+    theta = kin.full_joint_angles(spec, theta)
     origin = torch.as_tensor(spec.frame_origin, dtype=dt)
     axis = torch.as_tensor(spec.frame_axis, dtype=dt)
     world = []
@@ -52,7 +53,7 @@ def link_jacobian(spec, theta: torch.Tensor) -> torch.Tensor:
     B, dt = theta.shape[0], theta.dtype
     world = _frame_worlds(spec, theta)
     axis = torch.as_tensor(spec.frame_axis, dtype=dt)
-    J = spec.n_dofs
+    J = spec.n_nodes
     out = torch.zeros(B, len(spec.link_frame), 6, J, dtype=dt)
     for li, lf in enumerate(spec.link_frame):
         o = world[int(lf)][:, :3, 3]
@@ -68,7 +69,9 @@ def link_jacobian(spec, theta: torch.Tensor) -> torch.Tensor:
                 else:
                     out[:, li, :3, j] = a
             f = int(spec.frame_parent[f])
-    return out
+    # coupled hands: the reference's jacobian_fnc folds the tree-joint columns into the actuated ones (ability_hand.py:
+    # 33-40: active = J[..., [0,2,4,6,8,9]] + mult * J[..., [1,3,5,7]]; panda.py:17-26: J[...,0] + J[...,1]) = J_tree C
+    return out @ torch.as_tensor(spec.coupling, dtype=dt)
 
 
 def contact_points_hand_frame(spec, theta, idx):

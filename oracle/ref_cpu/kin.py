@@ -35,6 +35,16 @@ def _axis_angle(axis: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
     return eye + s * K + (1 - c) * (K @ K)
 
 
+def full_joint_angles(spec, theta: torch.Tensor) -> torch.Tensor:
+    """Actuated joint values (B,J) -> values of all N moving joints of the tree.  Coupled hands restate the
+    ``joint_calc_fnc`` of reference hands/ability_hand.py:9-30 (q2 = 1.05851325 q1) and hands/panda.py:6-14 (both fingers
+    follow one value): theta_tree = C theta + c0; identity for the other hands."""
+    C = torch.as_tensor(spec.coupling, dtype=theta.dtype)
+    if C.shape[0] == C.shape[1] and torch.equal(C, torch.eye(C.shape[0], dtype=theta.dtype)):
+        return theta
+    return theta @ C.T + torch.as_tensor(spec.coupling_offset, dtype=theta.dtype)
+
+
 def forward_kinematics(spec, theta: torch.Tensor) -> torch.Tensor:
     """Joint angles (B,J) -> mesh-link transforms (B,L,4,4) in the hand base frame.
 
@@ -45,6 +55,7 @@ def forward_kinematics(spec, theta: torch.Tensor) -> torch.Tensor:
     """
     B = theta.shape[0]
     dt = theta.dtype
+    theta = full_joint_angles(spec, theta)
     F = len(spec.frame_names)
     origin = torch.as_tensor(spec.frame_origin, dtype=dt)
     axis = torch.as_tensor(spec.frame_axis, dtype=dt)

@@ -61,11 +61,14 @@ def test_product_does_not_import_oracle():
 def test_hand_specs():
     from graspqp_amd.hands import AVAILABLE_HANDS, get_hand_spec
 
-    expect = {"allegro": (16, 14, 92, 25), "shadow_hand": (24, 18, 80, 22), "robotiq3": (11, 12, 48, 12)}
+    expect = {"allegro": (16, 14, 92, 25), "shadow_hand": (24, 18, 80, 22), "robotiq3": (11, 12, 48, 12),
+              "ability_hand": (6, 11, 64, 19), "panda": (1, 3, 16, 2)}
+    assert sorted(AVAILABLE_HANDS) == sorted(expect)
     for h in AVAILABLE_HANDS:
         s = get_hand_spec(h)
         assert (s.n_dofs, s.n_links, s.n_contact_candidates, s.n_spheres) == expect[h]
-        assert (s.node_parent < np.arange(s.n_dofs)).all()
+        assert (s.node_parent < np.arange(s.n_nodes)).all()
+        assert s.coupling.shape == (s.n_nodes, s.n_dofs) and s.is_coupled == (h in ("ability_hand", "panda"))
         assert np.allclose(np.linalg.norm(s.cand_nrm, axis=1), 1.0, atol=1e-4)
         assert (s.joints_lower < s.joints_upper).all()
 
@@ -202,3 +205,35 @@ def test_integration_aliases_import_the_reference_modules():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_coupled_hands_and_grasp_types():
+    """hands/ability_hand.py:9-41, hands/panda.py:6-26 (joint coupling) and hand_model.py:438-451,550-589 (grasp types)."""
+    from graspqp_amd.hands import get_hand_spec
+
+    ab = get_hand_spec("ability_hand")
+    assert ab.full_joint_names == ["index_q1", "index_q2", "middle_q1", "middle_q2", "pinky_q1", "pinky_q2", "ring_q1", "ring_q2",
+                                   "thumb_q1", "thumb_q2"]
+    th = np.array([[0.1, 0.2, 0.3, 0.4, 0.5, 0.6]])
+    m = 1.05851325
+    np.testing.assert_allclose(ab.full_joint_angles(th)[0], [0.1, 0.1 * m, 0.2, 0.2 * m, 0.3, 0.3 * m, 0.4, 0.4 * m, 0.5, 0.6], rtol=1e-6)
+    pa = get_hand_spec("panda")
+    np.testing.assert_allclose(pa.full_joint_angles(np.array([[0.03]]))[0], [0.03, 0.03])
+    al = get_hand_spec("allegro")
+    assert "pinch" in al.grasp_types() or len(al.grasp_types()) > 0
+    for gt in al.grasp_types():
+        try:
+            sub = get_hand_spec("allegro", grasp_type=gt)
+        except NotImplementedError:
+            continue  # asks for more candidates per link than the reference's dump holds
+        links = set(np.asarray(al.link_names)[np.unique(sub.cand_link)])
+        import json
+
+        assert links <= set(json.loads(al.eigengrasps)[gt]) and 0 < sub.n_contact_candidates <= al.n_contact_candidates
+        if gt == "pinch":
+            for i, jn in enumerate(sub.joint_names):
+                folded = ("middle" in jn or "ring" in jn) and "joint_0" not in jn
+                assert sub.default_state[i] == (al.joints_upper[i] if folded else al.default_state[i])
+    with pytest.raises(ValueError):
+        get_hand_spec("allegro", grasp_type="no_such_type")
+    assert get_hand_spec("allegro", grasp_type="all").n_contact_candidates == 92

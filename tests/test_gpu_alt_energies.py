@@ -210,3 +210,59 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     hm2.set_parameters(hp.detach(), torch.tensor(g["contact_idx"]).cuda())
     sp = hm2.get_surface_points()
     assert sp.shape == (n_obj * be, 512, 3) and torch.isfinite(sp).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# coupled-joint hands and grasp-type subsets
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hand_name,grasp_type", [("ability_hand", None), ("panda", None), ("allegro", "pinch"),
+                                                  ("ability_hand", "precision")])
+def test_coupled_hands_and_grasp_types_whole_iteration(gq, hand_name, grasp_type):
+    """Energy + gradient of the whole composition for hands whose tree joints follow fewer actuated ones (ability_hand:
+    q2 = 1.0585 q1 on four fingers; panda: both fingers on one value -- reference hands/ability_hand.py, panda.py) and
+    for grasp-type contact subsets, against the fp64 oracle; then iterations (graph == eager)."""
+    spec = get_hand_spec(hand_name, grasp_type=grasp_type)
+    n_obj, be, n = 2, 5, 4 if hand_name == "panda" else 12
+    B = n_obj * be
+    fvs = [meshes.superquadric(9 + i, 32, 16) for i in range(n_obj)]
+    sps = [meshes.surface_points(f, 600, oversample=4, seed=3 + i) for i, f in enumerate(fvs)]
+    g0 = torch.Generator().manual_seed(17)
+    t = torch.nn.functional.normalize(torch.randn(B, 3, generator=g0, dtype=torch.float64), dim=-1) * 0.09
+    th = torch.tensor(spec.default_state, dtype=torch.float64)[None] + 0.2 * torch.randn(B, spec.n_dofs, generator=g0, dtype=torch.float64)
+    th[0] = torch.tensor(spec.joints_upper, dtype=torch.float64) + 0.05  # E_joints active on the actuated joints
+    hp = torch.cat([t, torch.randn(B, 6, generator=g0, dtype=torch.float64), th], 1)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=g0)
+    assert hp.shape[1] == 9 + spec.n_dofs and spec.n_nodes >= spec.n_dofs
+    hand = gq.ops.HandHandle(spec)
+    st = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, seed=5)
+    terms, total, grad = st.evaluate(hp.float().cuda(), idx.cuda())
+    torch.cuda.synchronize()
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject(fvs, sps, be, torch.float64)
+    hpo = hp.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    w0 = {"E_dis": 100.0, "E_fc": 0.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    lo = ref_cpu.calculate_energy(oh, oo, box_form=True)
+    for k in ("E_dis", "E_pen", "E_spen", "E_joints"):
+        np.testing.assert_allclose(terms[k].cpu().numpy(), lo[k].detach().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    assert float(lo["E_joints"][0]) > 0
+    rel = np.abs(terms["E_fc"].cpu().numpy() - lo["E_fc"].detach().numpy()) / np.abs(lo["E_fc"].detach().numpy())
+    assert np.median(rel) < 1e-4 and rel.max() < 5e-3
+    s0 = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, weights=w0)
+    _, _, g0_ = s0.evaluate(hp.float().cuda(), idx.cuda())
+    sum(w0[k] * lo[k] for k in w0 if w0[k] != 0.0).sum().backward()
+    go = oh.hand_pose.grad.numpy()
+    assert np.linalg.norm(g0_.cpu().numpy() - go) <= 5e-3 * np.linalg.norm(go)
+    outs = []
+    for rep in range(2):
+        s2 = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, seed=5)
+        s2.reset(hp.float().cuda(), idx.cuda())
+        if rep == 1:
+            s2.capture(iters=2)
+        for _ in range(4):
+            s2.step()
+        s2.flush()
+        torch.cuda.synchronize()
+        outs.append((s2.energy.clone(), s2.hand_pose.clone(), s2.contact_idx.clone()))
+    assert torch.isfinite(outs[0][0]).all() and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert int(outs[0][2].max()) < spec.n_contact_candidates

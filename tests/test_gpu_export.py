@@ -35,7 +35,7 @@ def _pose(spec, B, seed, spread=0.12):
     return torch.cat([t, six, th], 1)
 
 
-@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3"])
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3", "ability_hand", "panda"])
 def test_explicit_jacobians(gq, hand_name):
     from graspqp_amd.core.hand_model import HandModel
 
@@ -67,7 +67,8 @@ def test_explicit_jacobians(gq, hand_name):
     assert (g_explicit - g_bwd).norm() <= 1e-4 * g_bwd.norm()
 
 
-@pytest.mark.parametrize("hand_name,n", [("allegro", 4), ("allegro", 12), ("shadow_hand", 16), ("robotiq3", 12)])
+@pytest.mark.parametrize("hand_name,n", [("allegro", 4), ("allegro", 12), ("shadow_hand", 16), ("robotiq3", 12),
+                                         ("ability_hand", 12), ("panda", 4)])
 def test_required_joint_velocities(gq, hand_name, n):
     """HandModel.get_req_joint_velocities: n = 4 on Allegro has 3n < n_dofs, where the reference's pinv takes its
     right-inverse branch -- the same matrix as the left form the kernel solves."""

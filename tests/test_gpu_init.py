@@ -39,7 +39,7 @@ def _hull_tuple(hull_fvs):
     return fv, cdf, off
 
 
-@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3"])
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3", "ability_hand", "panda"])
 def test_init_kernels_match_oracle_on_injected_draws(gq, hand_name):
     from graspqp_amd.core.initializations import convex_hull_poses
 

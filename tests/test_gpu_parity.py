@@ -219,7 +219,7 @@ def _rand_pose(spec, B, seed, spread=0.12):
     return torch.cat([t, six, th], 1)
 
 
-@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3"])
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "robotiq3", "ability_hand", "panda"])
 def test_fk_contacts_forward_backward(gq, hand_name):
     spec = get_hand_spec(hand_name)
     B, n = 6, 12

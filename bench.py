@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_rows", type=int, default=8)
     ap.add_argument("--cpu_reps", type=int, default=5)
+    ap.add_argument("--point_grid", type=int, default=8, help="cells per axis of the surface-point grid of the link-driven "
+                    "penetration query (0: the point-driven query of round 1, for A/B runs)")
     ap.add_argument("--selftest_ranks", action="store_true",
                     help="launcher / rendezvous / collective sequence only (no GPU work): used by the CPU test of --gpus N")
     return ap.parse_args(argv)
@@ -222,7 +224,7 @@ def rank_main(args):
     B = len(my_objs) * args.batch_size
     hand = ops.HandHandle(spec)
     st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact,
-                      fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank)
+                      fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank, point_grid=args.point_grid)
     hps, idxs = zip(*[make_initial_state(spec, f, args.batch_size, args.n_contact, 1000 + o) for f, o in zip(fvs, my_objs)])
     st.reset(torch.cat(hps).cuda(), torch.cat(idxs).cuda())
 
@@ -308,16 +310,23 @@ def rank_main(args):
         st._eval_fk(st.hand_pose, st.contact_idx, stream)
         _C.call("gq_sdf_forward_meshset", st.objs.handle, _C.f32(st.cpts), B * st.n, st.be * st.n, _C.f32(st.d2),
                 _C.i32(st.sgn), _C.f32(st.onrm), _C.f32(st.closest), stream)
-        _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(st.surf), st.n_obj, st.P, st.be, _C.f32(st.hand_pose),
-                st.D, _C.f32(st.Rg), _C.f32(st.link_T), 1, _C.f32(st.pen_dis), _C.i32(st.pen_link), _C.f32(st.pen_gvec),
-                None, 0, None, None, stream)
+        if st.grid is not None:
+            _C.call("gq_hand_pen_forward_cells", hand.links.handle, st.grid.handle, _C.f32(st.surf), st.n_obj, st.P, st.be,
+                    _C.f32(st.hand_pose), st.D, _C.f32(st.Rg), _C.f32(st.link_T), _C.f32(st.pen_dis), _C.i32(st.pen_link),
+                    _C.f32(st.pen_gvec), None, None, stream)
+        else:
+            _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(st.surf), st.n_obj, st.P, st.be, _C.f32(st.hand_pose),
+                    st.D, _C.f32(st.Rg), _C.f32(st.link_T), 1, _C.f32(st.pen_dis), _C.i32(st.pen_link), _C.f32(st.pen_gvec),
+                    None, 0, None, None, stream)
         torch.cuda.synchronize()
         _C.call("gq_debug_set_pen_counters", None)
         c = [int(v) for v in cnt.tolist()]
         executed = {"object_sdf": {"queries": c[1], "cluster_visits": c[0], "point_triangle_tests": c[0] * 64,
                                    "max_visits_per_query": c[2]},
                     "hand_pen": {"point_link_pairs": B * st.P * hand.L, "pairs_reaching_candidates": c[4],
-                                 "point_triangle_tests": c[5], "pairs_ranked_inline": c[6], "blocks": c[7]}}
+                                 "point_triangle_tests": c[5], "pairs_ranked_inline": c[6], "blocks": c[7],
+                                 "link_cell_pairs_walked": c[0] if st.grid is not None else None,
+                                 "query": "link-driven (point grid)" if st.grid is not None else "point-driven"}}
     except Exception as e:  # diagnostics must never cost the bench line
         executed = {"error": repr(e)}
     st._graph = g

@@ -26,6 +26,14 @@ struct gqMeshSet {
 };
 
 
+// ---- uniform grid over the surface points of every object (set-up data of the cell-driven penetration query) --------
+struct gqPointGrid {
+  float* box_dev;        // (n_obj,8): lo.xyz, -, cells per metre x y z, -
+  int32_t* start_dev;    // (n_obj, G^3 + 1)
+  uint16_t* pts_dev;     // (n_obj, P)
+  int n_obj, P, G;
+};
+
 // ---- hand penetration: max over links of the signed distance (inside positive) of object surface points ----------
 // link_T: (B, L, 12) row-major [R | t] of each mesh link in the hand frame; Rg (B,9) global rotation; hand_pose (B,D)
 // holds the global translation in its first three entries.  Outputs per (row, point): dis, argmax link, and
@@ -49,6 +57,11 @@ struct GqPenArgs {
   int32_t* link;  // (B, P)
   float* gvec;    // (B, P, 3)
   uint64_t* span;  // optional [min start, max end] of the launch in 100 MHz s_memrealtime ticks
+  // optional uniform grid over every object's surface points (gqPointGrid): the cell-driven query gq_pen_cells_body
+  const float* grid_box;       // (n_obj,8): lo.xyz, -, cells per metre x y z, -
+  const int32_t* grid_start;   // (n_obj, G^3 + 1) prefix offsets into grid_pts
+  const uint16_t* grid_pts;    // (n_obj, P) point indices grouped by cell
+  int G;
   unsigned long long* dbg;  // optional counters (8 words, gq_debug_set_pen_counters): [0] needing (point,link) pairs,
                             // [1] (wave,link) evaluations, [2] (wave,sub-cluster) evaluations, [3] waves (AABB / queue
                             // kernels); gq_pen_grid_body: [4] entries = (point,link) pairs that reach a non-empty
@@ -285,6 +298,233 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   }
 }
 
+// ---- the same query driven by the LINKS instead of the points ------------------------------------------------------------
+// gq_pen_grid_body tests every (point, link) pair of a row -- 2500 x 14 sphere tests of which ~0.1 % survive.  Here a row's
+// block walks, per link, only the cells of a coarse uniform grid over the object's surface points (gqPointGrid, built
+// once per object) that the link's box can touch: the link AABB's eight corners are taken to the world frame, their
+// bounding box gives a cell range, and only the points filed under those cells are tested.  The work is proportional to
+// the overlaps, not to points x links.  From the point test on (link frame, AABB, occupancy voxel, candidate faces,
+// ranking, finish, max over links) it is the code of gq_pen_grid_body, so the two produce the same dis / link / gvec.
+// One block of 256 threads = one row; entries / items / per-point keys live in LDS.  If a row has more than GQ_PC_ECAP
+// (point, link) overlaps (a hand deep inside the object) the block falls back to gq_pen_grid_body for that row.
+#define GQ_PC_ECAP 1024
+#define GQ_PC_ICAP 4096
+#define GQ_PC_PMAX 4096
+__host__ __device__ inline size_t gq_pen_cells_lds_bytes(int L, int P) {
+  const size_t mine = (size_t)GQ_PC_ECAP * (sizeof(GqPgEntry) + 8) + (size_t)P * 8 + (size_t)GQ_PC_ICAP * 4 + 32 +
+                      (size_t)L * 24 * 4 + (size_t)L * 8 * 4 + (size_t)(L + 1) * 4;
+  const size_t old = gq_pen_grid_lds_bytes(L);
+  return (mine > old ? mine : old) + 16;
+}
+__device__ __forceinline__ void gq_pen_cells_body(const GqPenArgs& g, int row, char* lds) {
+  unsigned long long* s_ekey = reinterpret_cast<unsigned long long*>(lds);
+  unsigned long long* s_pkey = s_ekey + GQ_PC_ECAP;
+  GqPgEntry* s_ent = reinterpret_cast<GqPgEntry*>(s_pkey + g.P);
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_ent + GQ_PC_ECAP);
+  float* s_ecl = reinterpret_cast<float*>(s_item);  // after phase B: closest point + dis per entry (4 floats; ICAP >= ECAP x 4)
+  int* s_cnt = reinterpret_cast<int*>(s_item + GQ_PC_ICAP);  // [0] entries [1] items [2] overflow flag [3..7] diagnostics
+  float* s_link = reinterpret_cast<float*>(s_cnt + 8);
+  int* s_rng = reinterpret_cast<int*>(s_link + g.L * 24);  // per link: ix0 iy0 iz0 nx ny nz - -
+  int* s_pref = s_rng + g.L * 8;                            // (L+1) prefix of cells per link
+  const int tid = threadIdx.x;
+  const int obj = row / g.batch_each;
+  const float* hp = g.hand_pose + (size_t)row * g.D;
+  const float* R = g.Rg + (size_t)row * 9;
+  if (g.span && tid == 0) gq_span_open(g.span, (unsigned)row);
+  for (int i = tid; i < g.L * 24; i += 256) {
+    const int l = i / 24, k = i % 24;
+    float v = 0.0f;
+    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
+    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
+    else if (k == 20) v = g.occ_invz[l];
+    s_link[i] = v;
+  }
+  if (tid < 8) s_cnt[tid] = 0;
+  for (int pt = tid; pt < g.P; pt += 256) s_pkey[pt] = 0ull;
+  const int G = g.G;
+  const float* gb = g.grid_box + (size_t)obj * 8;
+  if (tid < g.L) {  // cell range of link `tid`: world bounding box of the eight corners of its AABB
+    const int l = tid;
+    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
+    const float* bb = g.aabb + l * 8;
+    float lo[3] = {GQ_INF_F, GQ_INF_F, GQ_INF_F}, hi[3] = {-GQ_INF_F, -GQ_INF_F, -GQ_INF_F};
+    for (int c = 0; c < 8; ++c) {
+      const gq3 q = gq_mk((c & 1) ? bb[4] : bb[0], (c & 2) ? bb[5] : bb[1], (c & 4) ? bb[6] : bb[2]);
+      const gq3 qh = gq_mk(T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3], T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7],
+                           T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11]);
+      const gq3 qw = gq_mv(R, qh) + gq_mk(hp[0], hp[1], hp[2]);
+      lo[0] = fminf(lo[0], qw.x); hi[0] = fmaxf(hi[0], qw.x);
+      lo[1] = fminf(lo[1], qw.y); hi[1] = fmaxf(hi[1], qw.y);
+      lo[2] = fminf(lo[2], qw.z); hi[2] = fmaxf(hi[2], qw.z);
+    }
+    int c0[3], n[3];
+    bool any = g.off[l + 1] > g.off[l];
+    for (int k = 0; k < 3; ++k) {
+      // a point p is filed under floor((p - lo_grid) * cells_per_metre); one thousandth of a cell of slack on both sides
+      // covers the rounding of the corner transforms (the point test itself is exact and repeated below)
+      const float a = (lo[k] - gb[k]) * gb[4 + k] - 1e-3f, b = (hi[k] - gb[k]) * gb[4 + k] + 1e-3f;
+      const int i0 = max((int)floorf(a), 0), i1 = min((int)floorf(b), G - 1);
+      c0[k] = i0;
+      n[k] = i1 - i0 + 1;
+      any = any && (b >= 0.0f) && (a < (float)G) && n[k] > 0;
+    }
+    int* r = s_rng + l * 8;
+    r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2];
+    r[3] = any ? n[0] : 0; r[4] = any ? n[1] : 0; r[5] = any ? n[2] : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < g.L; ++l) {
+      s_pref[l] = acc;
+      acc += s_rng[l * 8 + 3] * s_rng[l * 8 + 4] * s_rng[l * 8 + 5];
+    }
+    s_pref[g.L] = acc;
+  }
+  __syncthreads();
+  const int n_pairs = s_pref[g.L];
+  const int32_t* cstart = g.grid_start + (size_t)obj * (G * G * G + 1);
+  const uint16_t* cpts = g.grid_pts + (size_t)obj * g.P;
+  // ---- A: (link, cell) pairs -> points -> entries -------------------------------------------------------------------------
+  for (int pair = tid; pair < n_pairs; pair += 256) {
+    int l = 0;
+    while (s_pref[l + 1] <= pair) ++l;
+    const int* r = s_rng + l * 8;
+    int q = pair - s_pref[l];
+    const int cx = r[0] + q % r[3];
+    q /= r[3];
+    const int cy = r[1] + q % r[4], cz = r[2] + q / r[4];
+    const int cid = (cz * G + cy) * G + cx;
+    const int k0 = cstart[cid], k1 = cstart[cid + 1];
+    if (k1 <= k0) continue;
+    const float* T = s_link + l * 24;
+    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const float* bb = T + 12;
+    for (int k = k0; k < k1; ++k) {
+      const int pt = (int)cpts[k];
+      const float* sp = g.surf + ((size_t)obj * g.P + pt) * 3;
+      const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+      const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
+      if (!(gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
+      const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
+      const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
+      if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
+      const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
+      const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
+      if (len == 0u) continue;
+      if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
+      const int e = atomicAdd(&s_cnt[0], 1);
+      if (e >= GQ_PC_ECAP) {  // too many overlaps for the LDS lists: the whole row is redone by the dense query
+        s_cnt[2] = 1;
+        continue;
+      }
+      int ib = GQ_PC_ICAP;
+      if (len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
+      GqPgEntry en;
+      en.x = xl.x; en.y = xl.y; en.z = xl.z;
+      en.c0 = c0;
+      en.pt = (uint16_t)pt;
+      en.link = (uint16_t)l;
+      s_ent[e] = en;
+      if (ib + (int)len <= GQ_PC_ICAP) {
+        s_ekey[e] = ~0ull;
+        for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
+      } else {  // no room for its items: rank the candidates here, phase C finishes the winner like any other entry
+        if (g.dbg) atomicAdd(&s_cnt[4], 1);
+        for (int i = ib; i < GQ_PC_ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
+        const int f0 = g.off[l];
+        unsigned long long bk = ~0ull;
+        for (uint32_t c = 0; c < len; ++c) {
+          const unsigned fl = g.cand_idx[c0 + c];
+          const GqFace fc = g.rec[f0 + (int)fl];
+          const float d2 = gq_tri_rank(fc, gq_mk(xl.x - fc.r0.x, xl.y - fc.r0.y, xl.z - fc.r0.z));
+          const unsigned long long key = gq_rank_key(d2, (unsigned)__float_as_int(fc.r5.z) - (unsigned)f0, fl);
+          bk = key < bk ? key : bk;
+        }
+        s_ekey[e] = bk;
+      }
+    }
+  }
+  __syncthreads();
+  if (g.dbg && tid == 0) {
+    atomicAdd(&g.dbg[4], (unsigned long long)s_cnt[0]);
+    atomicAdd(&g.dbg[5], (unsigned long long)s_cnt[3]);
+    atomicAdd(&g.dbg[6], (unsigned long long)s_cnt[4] + (s_cnt[2] ? (unsigned long long)s_cnt[0] : 0ull));
+    atomicAdd(&g.dbg[7], 1ull);
+    atomicAdd(&g.dbg[0], (unsigned long long)n_pairs);
+  }
+  if (s_cnt[2]) {  // block-uniform
+    GqPenArgs h = g;
+    h.span = nullptr;
+    h.dbg = nullptr;
+    __syncthreads();
+    for (int bx = 0; bx < (g.P + 255) / 256; ++bx) {
+      gq_pen_grid_body<true>(h, bx, row, lds);
+      __syncthreads();
+    }
+    if (g.span && tid == 0) gq_span_close(g.span, (unsigned)row);
+    return;
+  }
+  const int n_ent = s_cnt[0], n_item = min(s_cnt[1], GQ_PC_ICAP);
+  // ---- B: one (entry, candidate) ranking per thread and step --------------------------------------------------------------
+  for (int i = tid; i < n_item; i += 256) {
+    const uint32_t it = s_item[i];
+    if (it == 0xffffffffu) continue;
+    const int e = (int)(it >> 16);
+    const GqPgEntry en = s_ent[e];
+    const int f0 = g.off[en.link];
+    const unsigned fl = g.cand_idx[en.c0 + (it & 0xffffu)];
+    const GqFace fc = g.rec[f0 + (int)fl];
+    const float d2 = gq_tri_rank(fc, gq_mk(en.x - fc.r0.x, en.y - fc.r0.y, en.z - fc.r0.z));
+    const unsigned orig = (unsigned)__float_as_int(fc.r5.z) - (unsigned)f0;
+    atomicMin(&s_ekey[e], gq_rank_key(d2, orig, fl));
+  }
+  __syncthreads();
+  // ---- C: finish the winner of every entry; penetrating entries compete per point ----------------------------------------
+  for (int e = tid; e < n_ent; e += 256) {
+    const GqPgEntry en = s_ent[e];
+    const int f = g.off[en.link] + (int)(s_ekey[e] & 0xffffull);
+    const gq3 xl = gq_mk(en.x, en.y, en.z);
+    const GqSdfOut o = gq_tri_finish(g.rec[f], xl);
+    if (o.sign < 0) {
+      const float dis = sqrtf(o.dist2 + 1e-8f);
+      s_ecl[e * 4 + 0] = o.closest.x;
+      s_ecl[e * 4 + 1] = o.closest.y;
+      s_ecl[e * 4 + 2] = o.closest.z;
+      s_ecl[e * 4 + 3] = dis;
+      atomicMax(&s_pkey[en.pt], ((unsigned long long)__float_as_uint(dis) << 32) |
+                                    ((unsigned long long)(255 - (int)en.link) << 16) | (unsigned long long)e);
+    }
+  }
+  __syncthreads();
+  // ---- D: outputs (dis for every point; link / gradient only where a link is penetrated) ---------------------------------
+  for (int pt = tid; pt < g.P; pt += 256) {
+    const unsigned long long pk = s_pkey[pt];
+    const size_t o = (size_t)row * g.P + pt;
+    if (pk == 0ull) {
+      g.dis[o] = -1e30f;
+      continue;
+    }
+    const int e = (int)(pk & 0xffffull);
+    const float dis = s_ecl[e * 4 + 3];
+    const int l = (int)s_ent[e].link;
+    const float* T = s_link + l * 24;
+    const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const gq3 xl = gq_mk(s_ent[e].x, s_ent[e].y, s_ent[e].z);
+    const gq3 cl = gq_mk(s_ecl[e * 4], s_ecl[e * 4 + 1], s_ecl[e * 4 + 2]);
+    const gq3 gh = gq_mv(Rl, (1.0f / dis) * (xl - cl));
+    g.dis[o] = dis;
+    g.link[o] = l;
+    g.gvec[o * 3 + 0] = gh.x;
+    g.gvec[o * 3 + 1] = gh.y;
+    g.gvec[o * 3 + 2] = gh.z;
+  }
+  if (g.span) {
+    __syncthreads();
+    if (tid == 0) gq_span_close(g.span, (unsigned)row);
+  }
+}
+
 // Backward of the hand-penetration query for an upstream gradient w (B,P) on `dis`:
 //   link wrench (hand frame, about the hand origin): f_l -= w G, m_l -= w x_h x G     (G = gvec)
 //   gRt[0..2]  = sum w G   (so that grad_t = -R gsum)
@@ -485,7 +725,8 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
 // ---- host side: argument blocks of the penetration-only query and its fused-E_pen backward ---------------------------
 static inline int gq_pen_fill(const gqMeshSet* links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                               int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
-                              const float* link_T, float* dis, int32_t* link, float* gvec, uint64_t* span, GqPenArgs* out) {
+                              const float* link_T, float* dis, int32_t* link, float* gvec, uint64_t* span, GqPenArgs* out,
+                              const gqPointGrid* grid = nullptr) {
   GQ_REQUIRE(links && surface_points && hand_pose && Rg && link_T && dis && link && gvec, "hand_pen_forward: null");
   GQ_REQUIRE(n_obj > 0 && n_surface > 0 && batch_each > 0 && pose_dim >= 9, "hand_pen_forward: bad sizes");
   GqPenArgs a{};
@@ -511,7 +752,16 @@ static inline int gq_pen_fill(const gqMeshSet* links, const float* surface_point
   a.link = link;
   a.gvec = gvec;
   a.span = span;
-  GQ_REQUIRE(a.B <= 65535, "hand_pen_forward: B=%d exceeds grid.y limit", a.B);
+  if (grid) {
+    GQ_REQUIRE(grid->n_obj == (int)n_obj && grid->P == (int)n_surface, "hand_pen_forward: the point grid was built for "
+               "%d objects x %d points, not %lld x %lld", grid->n_obj, grid->P, (long long)n_obj, (long long)n_surface);
+    GQ_REQUIRE(n_surface <= GQ_PC_PMAX, "hand_pen_forward: the cell-driven query handles at most %d surface points", GQ_PC_PMAX);
+    a.grid_box = grid->box_dev;
+    a.grid_start = grid->start_dev;
+    a.grid_pts = grid->pts_dev;
+    a.G = grid->G;
+  }
+  GQ_REQUIRE(a.B <= 65535 || grid, "hand_pen_forward: B=%d exceeds grid.y limit", a.B);
   *out = a;
   return GQ_OK;
 }

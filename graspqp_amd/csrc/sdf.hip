@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
   gq_pen_grid_body<EVAL>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
 }
+__global__ __launch_bounds__(256) void gq_pen_cells_kernel(GqPenArgs g) {
+  extern __shared__ char gq_lds[];
+  gq_pen_cells_body(g, (int)blockIdx.x, gq_lds);
+}
 __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
   extern __shared__ char gq_lds[];
   gq_pen_bwd_body(g, (int)blockIdx.x, gq_lds);
@@ -905,6 +909,96 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   else
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+// Uniform grid over the surface points of every object (host build, set-up time).
+int gq_pointgrid_create(const float* surface_points_host, int64_t n_obj, int64_t n_surface, int cells_per_axis,
+                        gqPointGrid** out) {
+  GQ_REQUIRE(surface_points_host && out && n_obj > 0 && n_surface > 0 && n_surface <= 65535, "pointgrid_create: bad arguments");
+  const int G = cells_per_axis > 0 ? cells_per_axis : 8;
+  GQ_REQUIRE(G >= 1 && G <= 32, "pointgrid_create: cells_per_axis must be in 1..32");
+  const int NC = G * G * G;
+  const int P = (int)n_surface;
+  std::vector<float> box((size_t)n_obj * 8, 0.0f);
+  std::vector<int32_t> start((size_t)n_obj * (NC + 1), 0);
+  std::vector<uint16_t> pts((size_t)n_obj * P, 0);
+  std::vector<int> cell(P);
+  for (int64_t o = 0; o < n_obj; ++o) {
+    const float* sp = surface_points_host + (size_t)o * P * 3;
+    float lo[3] = {sp[0], sp[1], sp[2]}, hi[3] = {sp[0], sp[1], sp[2]};
+    for (int i = 0; i < P; ++i)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = sp[i * 3 + k] < lo[k] ? sp[i * 3 + k] : lo[k];
+        hi[k] = sp[i * 3 + k] > hi[k] ? sp[i * 3 + k] : hi[k];
+      }
+    float* b = box.data() + (size_t)o * 8;
+    for (int k = 0; k < 3; ++k) {
+      b[k] = lo[k];
+      const float ext = hi[k] - lo[k];
+      b[4 + k] = (float)G / (ext > 1e-9f ? ext : 1e-9f);
+    }
+    int32_t* st = start.data() + (size_t)o * (NC + 1);
+    for (int i = 0; i < P; ++i) {
+      int c[3];
+      for (int k = 0; k < 3; ++k) {
+        int v = (int)std::floor((sp[i * 3 + k] - b[k]) * b[4 + k]);
+        c[k] = v < 0 ? 0 : (v > G - 1 ? G - 1 : v);
+      }
+      cell[i] = (c[2] * G + c[1]) * G + c[0];
+      st[cell[i] + 1]++;
+    }
+    for (int c = 0; c < NC; ++c) st[c + 1] += st[c];
+    std::vector<int32_t> fill(st, st + NC);
+    uint16_t* pp = pts.data() + (size_t)o * P;
+    for (int i = 0; i < P; ++i) pp[fill[cell[i]]++] = (uint16_t)i;  // points of a cell in index order
+  }
+  gqPointGrid* g = new gqPointGrid();
+  g->n_obj = (int)n_obj;
+  g->P = P;
+  g->G = G;
+  g->box_dev = nullptr;
+  g->start_dev = nullptr;
+  g->pts_dev = nullptr;
+  GQ_CHECK_HIP(hipMalloc(&g->box_dev, box.size() * sizeof(float)));
+  GQ_CHECK_HIP(hipMalloc(&g->start_dev, start.size() * sizeof(int32_t)));
+  GQ_CHECK_HIP(hipMalloc(&g->pts_dev, pts.size() * sizeof(uint16_t)));
+  GQ_CHECK_HIP(hipMemcpy(g->box_dev, box.data(), box.size() * sizeof(float), hipMemcpyHostToDevice));
+  GQ_CHECK_HIP(hipMemcpy(g->start_dev, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  GQ_CHECK_HIP(hipMemcpy(g->pts_dev, pts.data(), pts.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  *out = g;
+  return GQ_OK;
+}
+
+int gq_pointgrid_destroy(gqPointGrid* g) {
+  if (!g) return GQ_OK;
+  if (g->box_dev) (void)hipFree(g->box_dev);
+  if (g->start_dev) (void)hipFree(g->start_dev);
+  if (g->pts_dev) (void)hipFree(g->pts_dev);
+  delete g;
+  return GQ_OK;
+}
+
+// The penetration-only query (gq_hand_pen_forward with penetration_only = 1) driven by the links through the point grid.
+int gq_hand_pen_forward_cells(const gqMeshSet* links, const gqPointGrid* grid, const float* surface_points, int64_t n_obj,
+                              int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
+                              const float* link_T, float* dis, int32_t* link, float* gvec, void* timer, uint64_t* span,
+                              void* stream) {
+  GQ_REQUIRE(grid, "hand_pen_forward_cells: null point grid");
+  GqPenArgs a{};
+  int rc0 = gq_pen_fill(links, surface_points, n_obj, n_surface, batch_each, hand_pose, pose_dim, Rg, link_T, dis, link,
+                        gvec, span, &a, grid);
+  if (rc0) return rc0;
+  GQ_REQUIRE(a.occ && a.cand_off, "hand_pen_forward_cells: the link mesh set has no voxel candidate lists (gq_meshset_build_occupancy)");
+  a.dbg = gq_pen_dbg_;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timer) {
+    e0 = ((hipEvent_t*)timer)[0];
+    e1 = ((hipEvent_t*)timer)[1];
+  }
+  hipExtLaunchKernelGGL(gq_pen_cells_kernel, dim3((unsigned)a.B), dim3(256), gq_pen_cells_lds_bytes(a.L, a.P),
+                        (hipStream_t)stream, e0, e1, 0, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenAr
     const int wv = (int)threadIdx.x / GQ_WAVE, row = b * GQ_HEAD_ROWS + wv;
     if (wv >= GQ_HEAD_ROWS || row >= f.B) return;
     gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6);
+  } else if (gx == 0) {  // link-driven query: one block per row (gqPenStepDesc.grid)
+    gq_pen_cells_body(p, b - nfc, gq_lds);
   } else {
     const int q = b - nfc;
     gq_pen_grid_body<true>(p, q % gx, q / gx, gq_lds);
@@ -85,7 +87,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   if (rc) return rc;
   GqPenArgs p{};
   rc = gq_pen_fill(pen->links, pen->surface_points, pen->n_obj, pen->n_surface, pen->batch_each, pen->hand_pose,
-                   pen->pose_dim, pen->Rg, pen->link_T, pen->dis, pen->link, pen->gvec, pen->span, &p);
+                   pen->pose_dim, pen->Rg, pen->link_T, pen->dis, pen->link, pen->gvec, pen->span, &p, pen->grid);
   if (rc) return rc;
   GQ_REQUIRE(p.occ && p.cand_off, "fc_pen_step: the link mesh set has no voxel candidate lists (gq_meshset_build_occupancy)");
   GQ_REQUIRE(p.B == f.B, "fc_pen_step: the two descriptors disagree on the batch (%d vs %d)", p.B, f.B);
@@ -94,7 +96,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
                        pen->Rg, nullptr, pen->link, pen->gvec, pen->link_wrench, pen->gRt, pen->dis, pen->w_pen, pen->e_pen,
                        pen->span, pen->span_acc, &pb);
   if (rc) return rc;
-  const int gx = (p.P + 255) / 256;
+  const int gx = pen->grid ? 0 : (p.P + 255) / 256;  // 0: the link-driven query, one block per row
   const bool two = f.nz > GQ_WAVE;
   GqSpenRole sp{};
   int n_sp = 0;
@@ -113,10 +115,11 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
     n_sp = (f.B + 3) / 4;
   }
   const int nfc = (f.B + GQ_HEAD_ROWS - 1) / GQ_HEAD_ROWS;
-  const size_t lds_a = std::max(gq_pen_grid_lds_bytes(p.L), (size_t)4 * f.n * 6 * sizeof(float));
+  const size_t lds_a = std::max(pen->grid ? gq_pen_cells_lds_bytes(p.L, p.P) : gq_pen_grid_lds_bytes(p.L),
+                                (size_t)4 * f.n * 6 * sizeof(float));
   const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
                                 n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);
-  const dim3 grid_a((unsigned)(nfc + gx * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
+  const dim3 grid_a((unsigned)(nfc + (pen->grid ? 1 : gx) * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
   if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx, nfc);
   else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx, nfc);
   GQ_LAUNCH_CHECK();

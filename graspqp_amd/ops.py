@@ -91,6 +91,29 @@ class MeshSet:
             pass
 
 
+class PointGrid:
+    """Coarse uniform grid over the surface points of every object (n_obj,P,3): set-up data of the link-driven
+    penetration query (gq_hand_pen_forward_cells)."""
+
+    def __init__(self, surface_points, cells_per_axis: int = 0):
+        sp = np.ascontiguousarray(np.asarray(surface_points.detach().cpu() if torch.is_tensor(surface_points) else surface_points,
+                                             dtype=np.float32))
+        self.n_obj, self.P = int(sp.shape[0]), int(sp.shape[1])
+        h = ctypes.c_void_p(0)
+        torch.cuda.current_device()
+        _C.call("gq_pointgrid_create", sp.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(self.n_obj), ctypes.c_int64(self.P),
+                int(cells_per_axis), ctypes.byref(h))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _C.lib().gq_pointgrid_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 # ----------------------------------------------------------------------------------------------------------
 # TorchSDF-compatible ops
 # ----------------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ class GraspStepper:
     def __init__(self, hand: ops.HandHandle, object_meshes: ops.MeshSet, surface_points: torch.Tensor, batch_each: int,
                  n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
                  penetration_only: bool = True, energy_type: str = "graspqp", optimizer: str = "mala_star",
-                 tdg_directions=None):
+                 tdg_directions=None, point_grid: int = 8):
         """energy_type: "graspqp" (default; the fused launches) | "dexgrasp" | "tdg" (scripts/fit.py:343-347; the
         force-closure term is then one extra launch after the contact terms).  optimizer: "mala_star" | "dexgraspnet"
         (AnnealingDexGraspNet, core/optimizer.py:11-149: no z-score in the temperature, no re-initialisation)."""
@@ -107,6 +107,10 @@ class GraspStepper:
         self._side = None
         self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
         self._can_fuse = self.penetration_only == 1 and energy_type == "graspqp"
+        # link-driven penetration query through a coarse grid over the objects' surface points (0 = the point-driven one)
+        self.grid = None
+        if self.penetration_only == 1 and point_grid and self.P <= 4096:
+            self.grid = ops.PointGrid(self.surf, int(point_grid))
         self.tdg_dirs = None
         if energy_type == "tdg":
             if tdg_directions is None:
@@ -142,6 +146,7 @@ class GraspStepper:
         pd.link_wrench, pd.gRt, pd.w_pen, pd.e_pen = (self.wrench.data_ptr(), self.gRt.data_ptr(), float(self.w["E_pen"]),
                                                       self.terms_new[2].data_ptr())
         pd.span, pd.span_acc = self._span.data_ptr(), self._span_acc.data_ptr()
+        pd.grid = self.grid.handle if self.grid is not None else None
         if self.S > 0:  # sphere centres + self penetration as a third role of the second fused launch
             pd.hand, pd.w_spen = self.hand.handle, float(self.w["E_spen"])
             pd.e_spen, pd.g_sphere_centers, pd.sphere_centers = (self.terms_new[3].data_ptr(), self.g_sph_w.data_ptr(),
@@ -217,10 +222,15 @@ class GraspStepper:
         the query (hipExtLaunchKernelGGL start/stop events).  The query also records its own execution span in
         100 MHz s_memrealtime ticks (64 shards of {min block start, max block end}); the backward launch folds them
         into ``_span_acc`` = {sum, launches}, which works inside a hipGraph replay too."""
-        _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
-                _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
-                _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
-                _C.ptr(self.pen_ws), self.pen_nb, timer, _C.ptr(self._span), st)
+        if self.grid is not None:
+            _C.call("gq_hand_pen_forward_cells", self.hand.links.handle, self.grid.handle, _C.f32(self.surf), self.n_obj, self.P,
+                    self.be, _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), _C.f32(self.pen_dis),
+                    _C.i32(self.pen_link), _C.f32(self.pen_gvec), timer, _C.ptr(self._span), st)
+        else:
+            _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
+                    _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
+                    _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
+                    _C.ptr(self.pen_ws), self.pen_nb, timer, _C.ptr(self._span), st)
         _C.call("gq_hand_pen_backward", self.L, _C.f32(self.surf), self.n_obj, self.P, self.be, _C.f32(pose), self.D,
                 _C.f32(self.Rg), None, _C.i32(self.pen_link), _C.f32(self.pen_gvec), _C.f32(self.wrench), _C.f32(self.gRt),
                 _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),

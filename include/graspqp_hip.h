@@ -128,6 +128,7 @@ int gq_tdg_energy(const float* contact_pts, const float* contact_normals, const 
  * without a cross-stream dependency.  Fields = the parameters of gq_fc_step / gq_hand_pen_forward /
  * gq_hand_pen_backward of the same names.                                                                      */
 typedef struct gqHand gqHand; /* declared with gq_hand_create below */
+typedef struct gqPointGrid gqPointGrid; /* gq_pointgrid_create, below */
 typedef struct gqFcStepDesc {
   const float* dist_sq; const int32_t* sign; const float* obj_dir; const float* closest;
   const float* contact_pts; const float* hand_normals; const float* cog;
@@ -145,6 +146,7 @@ typedef struct gqPenStepDesc {
   /* optional third role of the second launch: world sphere centres + self penetration (gq_self_pen_forward on the
    * centres of link_T), so that gq_fk_forward can be called without spheres; hand == NULL: absent               */
   const gqHand* hand; float w_spen; float* e_spen; float* g_sphere_centers; float* sphere_centers /* or NULL */;
+  const gqPointGrid* grid;                      /* optional: the query role runs link-driven (gq_hand_pen_forward_cells) */
 } gqPenStepDesc;
 int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream);
 
@@ -283,6 +285,18 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (
                         uint64_t* span /* NULL, or {min start, max end} in 100 MHz device ticks, pre-set to {~0, 0} */,
                         void* stream);
 int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes);
+/* The same penetration-only query (penetration_only = 1: dis exact where > 0, -1e30 elsewhere; link / gvec written only
+ * where dis > 0) driven by the LINKS: a coarse uniform grid over every object's surface points (gqPointGrid, set-up
+ * time; cells_per_axis 0 = default 8) lets a row's block test only the points filed under the cells a link's box can
+ * touch, so the work follows the overlaps instead of points x links.  Same dis / link / gvec as gq_hand_pen_forward.  */
+typedef struct gqPointGrid gqPointGrid;
+int gq_pointgrid_create(const float* surface_points_host /* (n_obj,P,3) */, int64_t n_obj, int64_t n_surface,
+                        int cells_per_axis, gqPointGrid** out);
+int gq_pointgrid_destroy(gqPointGrid* grid);
+int gq_hand_pen_forward_cells(const gqMeshSet* links, const gqPointGrid* grid, const float* surface_points, int64_t n_obj,
+                              int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
+                              const float* link_T, float* dis, int32_t* link, float* gvec, void* timer /* gqTimer or NULL */,
+                              uint64_t* span /* as gq_hand_pen_forward */, void* stream);
 /* diagnostics (NULL = off): 8 device words.  Stand-alone gq_hand_pen_forward (penetration_only = 1) adds [4] (point,
  * link) pairs that reach candidate evaluation, [5] executed point-triangle rankings, [6] pairs ranked inline because the
  * block's LDS lists were full, [7] blocks; gq_sdf_forward_meshset adds [0] 64-face cluster visits, [1] queries, sets

@@ -318,3 +318,86 @@ def test_hand_penetration_item_list_overflow(gq):
     do = oh.cal_distance(oo.surface_points_tensor).numpy()
     big = np.abs(dis1.cpu().numpy() - do)[do > 1e-6] > 3e-6
     assert big.mean() < 2e-3, big.mean()
+
+
+@pytest.mark.parametrize("scene", ["bench", "deep", "fingertip"])
+@pytest.mark.parametrize("cells", [8, 4, 16])
+def test_link_driven_query_equals_point_driven(gq, scene, cells):
+    """gq_hand_pen_forward_cells (a row's block walks the grid cells each link box can touch) against the point-driven
+    query gq_hand_pen_forward(penetration_only = 1) it replaces in the fused launches and against the exact query
+    (penetration_only = 0): bench-like poses, hands deep inside the object (> GQ_PC_ECAP overlaps per row: the dense
+    fall-back) and the fingertip scene (item-list overflow: inline ranking)."""
+    from bench import make_initial_state
+
+    spec = get_hand_spec("allegro")
+    C, f32, i32 = gq.C.call, gq.C.f32, gq.C.i32
+    if scene == "fingertip":
+        n_obj, be, P = 1, 3, 1024
+        fvs = [meshes.icosphere(3, 0.004)]
+        sps = [meshes.surface_points(fvs[0], P, oversample=4, seed=1)]
+        th = torch.tensor(spec.default_state, dtype=torch.float64)[None].repeat(be, 1)
+        hp = torch.cat([torch.zeros(be, 3, dtype=torch.float64), torch.tensor([[1.0, 0, 0, 0, 1, 0]], dtype=torch.float64).repeat(be, 1), th], 1)
+        oh = omodels.OracleHand(spec, torch.float64)
+        oh.set_parameters(hp, torch.zeros(be, 4, dtype=torch.long))
+        lf = spec.link_faces(3).reshape(-1, 3)
+        c = torch.tensor(0.5 * (lf.min(0) + lf.max(0)), dtype=torch.float64)
+        T = oh.current_status[:, 3]
+        hp[:, :3] = -(T[:, :3, :3] @ c + T[:, :3, 3])
+        hp = hp.float()
+    else:
+        n_obj, be, P = 2, 48, 2500
+        fvs = [meshes.superquadric(o) for o in range(n_obj)]
+        sps = [meshes.surface_points(f, P, oversample=4, seed=42) for f in fvs]
+        hp = torch.cat([make_initial_state(spec, f, be, 12, 1000 + o)[0] for o, f in enumerate(fvs)])
+        if scene == "deep":
+            hp[:, :3] *= 0.15  # hands inside the objects: thousands of (point, link) overlaps per row
+        else:
+            hp[::5, :3] *= 0.5
+    B = n_obj * be
+    hand = gq.ops.HandHandle(spec)
+    surf = torch.tensor(np.stack(sps)).cuda().contiguous()
+    grid = gq.ops.PointGrid(surf, cells)
+    pose = hp.cuda().contiguous()
+    idx = torch.zeros(B, 1, dtype=torch.long, device="cuda")
+    Rg, LT, *_ = gq.ops.fk_contacts(pose, idx, hand)
+    Rg, LT = Rg.reshape(B, 9).contiguous(), LT.reshape(B, hand.L, 12).contiguous()
+
+    def run(mode):
+        dis = torch.empty(B, P, device="cuda")
+        link = torch.zeros(B, P, dtype=torch.int32, device="cuda")
+        gvec = torch.zeros(B, P, 3, device="cuda")
+        if mode == "cells":
+            C("gq_hand_pen_forward_cells", hand.links.handle, grid.handle, f32(surf), n_obj, P, be, f32(pose), pose.shape[1],
+              f32(Rg), f32(LT), f32(dis), i32(link), f32(gvec), None, None, gq.C.stream_ptr())
+        else:
+            C("gq_hand_pen_forward", hand.links.handle, f32(surf), n_obj, P, be, f32(pose), pose.shape[1], f32(Rg), f32(LT),
+              int(mode), f32(dis), i32(link), f32(gvec), None, 0, None, None, gq.C.stream_ptr())
+        torch.cuda.synchronize()
+        return dis, link, gvec
+
+    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    C("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
+    try:
+        d_c, l_c, g_c = run("cells")
+    finally:
+        C("gq_debug_set_pen_counters", None)
+    d_p, l_p, g_p = run(1)
+    d_0, l_0, g_0 = run(0)
+    pos = d_p > 0
+    assert pos.sum() > 0, "scene must contain penetrating points"
+    assert torch.equal(d_c > 0, pos), "the two queries must find the same penetrating points"
+    # same arithmetic in two kernels: allow last-bit differences from instruction contraction, nothing more
+    torch.testing.assert_close(d_c[pos], d_p[pos], rtol=1e-6, atol=1e-9)
+    assert torch.equal(l_c[pos], l_p[pos])
+    torch.testing.assert_close(g_c[pos], g_p[pos], rtol=1e-5, atol=1e-7)
+    assert bool((d_c[~pos] == -1e30).all())
+    big = (d_c[pos] - d_0[pos]).abs() > 3e-6  # against the exact query: near-tied faces may swap (tests/test_gpu_parity.py)
+    assert big.float().mean() < 2e-3
+    entries, rankings, inline, blocks, pairs = int(cnt[4]), int(cnt[5]), int(cnt[6]), int(cnt[7]), int(cnt[0])
+    assert blocks == B and entries >= int(pos.sum())
+    if scene == "deep":
+        assert inline > 0, "the deep scene must overflow the entry list of some row (dense fall-back)"
+    if scene == "fingertip":
+        assert inline > 0, "the fingertip scene must overflow the item list (inline ranking)"
+    if scene == "bench":
+        assert pairs < 0.05 * B * P * hand.L, "the link-driven walk must visit far fewer pairs than points x links"

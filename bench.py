@@ -56,8 +56,9 @@ def parse_args(argv=None):
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_rows", type=int, default=8)
     ap.add_argument("--cpu_reps", type=int, default=5)
-    ap.add_argument("--point_grid", type=int, default=8, help="cells per axis of the surface-point grid of the link-driven "
-                    "penetration query (0: the point-driven query of round 1, for A/B runs)")
+    ap.add_argument("--point_grid", type=int, default=0, help="cells per axis of the surface-point grid of the link-driven "
+                    "penetration query (A/B runs; 0 = the point-driven query, which is faster: one thread per point keeps far\n"
+                    "more independent loads in flight than one block per row)")
     ap.add_argument("--selftest_ranks", action="store_true",
                     help="launcher / rendezvous / collective sequence only (no GPU work): used by the CPU test of --gpus N")
     return ap.parse_args(argv)
@@ -317,7 +318,7 @@ def rank_main(args):
         else:
             _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(st.surf), st.n_obj, st.P, st.be, _C.f32(st.hand_pose),
                     st.D, _C.f32(st.Rg), _C.f32(st.link_T), 1, _C.f32(st.pen_dis), _C.i32(st.pen_link), _C.f32(st.pen_gvec),
-                    None, 0, None, None, stream)
+                    None, 0, None, None, _C.f32(st.patch), stream)
         torch.cuda.synchronize()
         _C.call("gq_debug_set_pen_counters", None)
         c = [int(v) for v in cnt.tolist()]

@@ -97,7 +97,7 @@ PenStepDesc = _struct("PenStepDesc", [
     ("links", "p"), ("surface_points", "p"), ("n_obj", "l"), ("n_surface", "l"), ("batch_each", "l"), ("hand_pose", "p"),
     ("pose_dim", "i"), ("Rg", "p"), ("link_T", "p"), ("dis", "p"), ("link", "p"), ("gvec", "p"), ("link_wrench", "p"),
     ("gRt", "p"), ("w_pen", "f"), ("e_pen", "p"), ("span", "p"), ("span_acc", "p"), ("hand", "p"), ("w_spen", "f"),
-    ("e_spen", "p"), ("g_sphere_centers", "p"), ("sphere_centers", "p"), ("grid", "p")])
+    ("e_spen", "p"), ("g_sphere_centers", "p"), ("sphere_centers", "p"), ("grid", "p"), ("patch_spheres", "p")])
 
 ProposeDesc = _struct("ProposeDesc", [
     ("hand_pose", "p"), ("grad", "p"), ("contact_idx", "p"), ("u_switch", "p"), ("new_idx", "p"), ("ema", "p"),

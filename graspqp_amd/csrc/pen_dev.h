@@ -62,6 +62,9 @@ struct GqPenArgs {
   const int32_t* grid_start;   // (n_obj, G^3 + 1) prefix offsets into grid_pts
   const uint16_t* grid_pts;    // (n_obj, P) point indices grouped by cell
   int G;
+  // optional (n_obj, ceil(P/256), 4): bounding sphere (centre, radius; object frame) of every 256-point slice of the
+  // surface points -- lets a block drop, before anything else, the links whose box cannot reach its slice
+  const float* patch;
   unsigned long long* dbg;  // optional counters (8 words, gq_debug_set_pen_counters): [0] needing (point,link) pairs,
                             // [1] (wave,link) evaluations, [2] (wave,sub-cluster) evaluations, [3] waves (AABB / queue
                             // kernels); gq_pen_grid_body: [4] entries = (point,link) pairs that reach a non-empty
@@ -108,7 +111,7 @@ __device__ __forceinline__ unsigned long long gq_rank_key(float d2, unsigned ori
 }
 // LDS of one block (bytes): entries, entry keys, items (re-used for the finished entries), point keys, counters, links
 __host__ __device__ inline size_t gq_pen_grid_lds_bytes(int L) {
-  return (size_t)GQ_PG_ECAP * (sizeof(GqPgEntry) + 8) + (size_t)GQ_PG_ICAP * 4 + 256 * 8 + 16 + (size_t)L * 28 * 4;
+  return (size_t)GQ_PG_ECAP * (sizeof(GqPgEntry) + 8) + (size_t)GQ_PG_ICAP * 4 + 256 * 8 + 32 + (size_t)L * 28 * 4;
 }
 // block = 256 threads = surface points [256 bx, 256 bx + 256) of `row`
 template <bool EVAL>
@@ -118,8 +121,8 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   GqPgEntry* s_ent = reinterpret_cast<GqPgEntry*>(s_pkey + 256);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_ent + GQ_PG_ECAP);  // entry << 16 | j
   float* s_ecl = reinterpret_cast<float*>(s_item);  // after phase B: closest point (link frame) + dis per entry
-  int* s_cnt = reinterpret_cast<int*>(s_item + GQ_PG_ICAP);
-  float* s_link = reinterpret_cast<float*>(s_cnt + 4);  // L x 24: link transform (12) + padded AABB (8) + occupancy
+  int* s_cnt = reinterpret_cast<int*>(s_item + GQ_PG_ICAP);  // 4 counters + the 64-bit mask of the links in reach
+  float* s_link = reinterpret_cast<float*>(s_cnt + 8);  // L x 24: link transform (12) + padded AABB (8) + occupancy
                                                         // z scale (1) + pad, then L x 4: bounding sphere of the link
                                                         // box in the hand frame (centre, r^2)
   float* s_sph = s_link + g.L * 24;
@@ -127,39 +130,62 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   const int pt = bx * 256 + tid;
   const unsigned block_id = (unsigned)(bx + row * ((g.P + 255) / 256));
   if (g.span && tid == 0) gq_span_open(g.span, block_id);
-  for (int i = tid; i < g.L * 24; i += 256) {
-    const int l = i / 24, k = i % 24;
-    float v = 0.0f;
-    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
-    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
-    else if (k == 20) v = g.occ_invz[l];
-    s_link[i] = v;
-  }
-  if (tid < g.L) {
-    const int l = tid;
-    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
-    const float* bb = g.aabb + l * 8;
-    const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
-    const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
-    s_sph[l * 4 + 0] = T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3];
-    s_sph[l * 4 + 1] = T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7];
-    s_sph[l * 4 + 2] = T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11];
-    s_sph[l * 4 + 3] = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
-  }
-  if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
-  s_pkey[tid] = 0ull;
   const bool ok = pt < g.P;
   const int obj = row / g.batch_each;
   const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
   const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+  if (tid < g.L) {
+    const int l = tid;
+    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
+    const float* bb = g.aabb + l * 8;
+    const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
+    const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
+    const gq3 sc = gq_mk(T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3], T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7],
+                         T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11]);
+    const float r2 = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
+    s_sph[l * 4 + 0] = sc.x;
+    s_sph[l * 4 + 1] = sc.y;
+    s_sph[l * 4 + 2] = sc.z;
+    s_sph[l * 4 + 3] = r2;
+    bool reach = r2 >= 0.0f;
+    if (g.patch && reach) {  // can the link's bounding sphere reach the bounding sphere of this block's slice at all?
+      const float* ps = g.patch + ((size_t)obj * ((g.P + 255) / 256) + bx) * 4;
+      const gq3 pc = gq_mtv(R, gq_mk(ps[0] - hp[0], ps[1] - hp[1], ps[2] - hp[2]));  // slice centre in the hand frame
+      const gq3 d = pc - sc;
+      const float rr = ps[3] + sqrtf(r2);
+      reach = gq_dot(d, d) <= rr * rr * 1.0001f + 1e-12f;
+    }
+    const unsigned long long m = __ballot(reach);  // links 0 .. L-1 sit in wavefront 0 (L <= 64)
+    if (tid == 0) *reinterpret_cast<unsigned long long*>(s_cnt + 4) = m;
+  }
+  if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
+  s_pkey[tid] = 0ull;
+  __syncthreads();
+  const unsigned long long lmask = *reinterpret_cast<const unsigned long long*>(s_cnt + 4);
+  if (lmask == 0ull) {  // no link can touch this slice: nothing penetrates
+    if (ok) g.dis[(size_t)row * g.P + pt] = -1e30f;
+    if (g.dbg && tid == 0) atomicAdd(&g.dbg[7], 1ull);
+    if (g.span && tid == 0) gq_span_close(g.span, block_id);
+    return;
+  }
+  for (int i = tid; i < g.L * 24; i += 256) {  // transforms / boxes of the links that can (the others are never read)
+    const int l = i / 24, k = i % 24;
+    if (!((lmask >> l) & 1ull)) continue;
+    float v = 0.0f;
+    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
+    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
+    else if (k == 20) v = g.occ_invz[l];
+    s_link[i] = v;
+  }
   __syncthreads();
   // ---- A: scan -------------------------------------------------------------------------------------------------
   float in_dis = 0.0f;  // result of entries this thread had to rank inline (capacity overflow)
   int in_link = -1;
   gq3 in_cl = gq_mk(0, 0, 0), in_xl = gq_mk(0, 0, 0);
-  for (int l = 0; l < g.L; ++l) {
+  for (unsigned long long rest = lmask; rest != 0ull; rest &= rest - 1ull) {  // links in reach of the slice, ascending
+    const int l = __builtin_ctzll(rest);
     // bounding sphere first (one LDS read, 7 VALU ops); the surface points are Morton-ordered, so a wavefront is a
     // compact patch of the object and most (wavefront, link) pairs end here
     const float4 sph = *reinterpret_cast<const float4*>(s_sph + l * 4);

@@ -865,12 +865,13 @@ int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float*
 int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int64_t n_obj, int64_t n_surface,
                         int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
                         int penetration_only, float* dis, int32_t* link, float* gvec, void* workspace,
-                        size_t workspace_bytes, void* timer, uint64_t* span, void* stream) {
+                        size_t workspace_bytes, void* timer, uint64_t* span, const float* patch_spheres, void* stream) {
   GqPenArgs a{};
   int rc0 = gq_pen_fill(links, surface_points, n_obj, n_surface, batch_each, hand_pose, pose_dim, Rg, link_T, dis, link,
                         gvec, span, &a);
   if (rc0) return rc0;
   a.dbg = gq_pen_dbg_;
+  a.patch = patch_spheres;
   const dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)a.B);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timer) {  // gqTimer: the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), not stream markers
@@ -909,6 +910,52 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
   else
     hipExtLaunchKernelGGL(gq_hand_pen_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, e0, e1, 0, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+// Bounding sphere of every 256-point slice of every object's surface points (set-up time; one block per slice).
+__global__ __launch_bounds__(256) void gq_patch_kernel(const float* __restrict__ surf, int P, float* __restrict__ out) {
+  __shared__ float s_red[4][6];
+  __shared__ float s_c[3];
+  const int obj = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, lane = gq_lane(), wv = tid / GQ_WAVE;
+  const int pt = bx * 256 + tid;
+  const bool ok = pt < P;
+  const float* sp = surf + ((size_t)obj * P + (ok ? pt : bx * 256)) * 3;  // out-of-range lanes repeat the slice's first point
+  const gq3 x = gq_mk(sp[0], sp[1], sp[2]);
+  float v[6] = {x.x, x.y, x.z, -x.x, -x.y, -x.z};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float m = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, GQ_WAVE));
+    if (lane == 0) s_red[wv][k] = m;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const float lo = fminf(fminf(s_red[0][tid], s_red[1][tid]), fminf(s_red[2][tid], s_red[3][tid]));
+    const float nh = fminf(fminf(s_red[0][3 + tid], s_red[1][3 + tid]), fminf(s_red[2][3 + tid], s_red[3][3 + tid]));
+    s_c[tid] = 0.5f * (lo - nh);
+  }
+  __syncthreads();
+  const gq3 d = x - gq_mk(s_c[0], s_c[1], s_c[2]);
+  float r = sqrtf(gq_dot(d, d));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, GQ_WAVE));
+  __syncthreads();
+  if (lane == 0) s_red[wv][0] = r;
+  __syncthreads();
+  if (tid == 0) {
+    float* o = out + ((size_t)obj * gridDim.x + bx) * 4;
+    o[0] = s_c[0]; o[1] = s_c[1]; o[2] = s_c[2];
+    o[3] = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0])) * 1.0001f + 1e-7f;
+  }
+}
+
+int gq_surface_patches(const float* surface_points, int64_t n_obj, int64_t n_surface, float* patch_spheres, void* stream) {
+  GQ_REQUIRE(surface_points && patch_spheres && n_obj > 0 && n_surface > 0, "surface_patches: bad arguments");
+  hipLaunchKernelGGL(gq_patch_kernel, dim3((unsigned)((n_surface + 255) / 256), (unsigned)n_obj), dim3(256), 0,
+                     (hipStream_t)stream, surface_points, (int)n_surface, patch_spheres);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

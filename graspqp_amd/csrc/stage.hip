@@ -89,6 +89,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   rc = gq_pen_fill(pen->links, pen->surface_points, pen->n_obj, pen->n_surface, pen->batch_each, pen->hand_pose,
                    pen->pose_dim, pen->Rg, pen->link_T, pen->dis, pen->link, pen->gvec, pen->span, &p, pen->grid);
   if (rc) return rc;
+  p.patch = pen->patch_spheres;
   GQ_REQUIRE(p.occ && p.cand_off, "fc_pen_step: the link mesh set has no voxel candidate lists (gq_meshset_build_occupancy)");
   GQ_REQUIRE(p.B == f.B, "fc_pen_step: the two descriptors disagree on the batch (%d vs %d)", p.B, f.B);
   GqPenBwdArgs pb{};

@@ -706,7 +706,7 @@ def _hand_pen_op(hand_pose: Tensor, surface_points: Tensor, batch_each: int, han
         pws = torch.zeros(pnb, dtype=torch.uint8, device=dev)  # queue counters must start at zero
     _C.call("gq_hand_pen_forward", h.links.handle, _C.f32(sp), n_obj, P, int(batch_each), _C.f32(hp), hp.shape[1],
             _C.f32(_c(Rg)), _C.f32(_c(LT)), int(penetration_only), _C.f32(dis), _C.i32(link), _C.f32(gvec), _C.ptr(pws), pnb,
-            None, None, _C.stream_ptr())
+            None, None, None, _C.stream_ptr())
     return dis, link, gvec
 
 

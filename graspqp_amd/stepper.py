@@ -27,7 +27,7 @@ class GraspStepper:
     def __init__(self, hand: ops.HandHandle, object_meshes: ops.MeshSet, surface_points: torch.Tensor, batch_each: int,
                  n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
                  penetration_only: bool = True, energy_type: str = "graspqp", optimizer: str = "mala_star",
-                 tdg_directions=None, point_grid: int = 8):
+                 tdg_directions=None, point_grid: int = 0):
         """energy_type: "graspqp" (default; the fused launches) | "dexgrasp" | "tdg" (scripts/fit.py:343-347; the
         force-closure term is then one extra launch after the contact terms).  optimizer: "mala_star" | "dexgraspnet"
         (AnnealingDexGraspNet, core/optimizer.py:11-149: no z-score in the temperature, no re-initialisation)."""
@@ -107,6 +107,10 @@ class GraspStepper:
         self._side = None
         self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
         self._can_fuse = self.penetration_only == 1 and energy_type == "graspqp"
+        # bounding spheres of the 256-point slices of the surface points: block-level link pre-cull of the penetration query
+        self.patch = torch.empty(self.n_obj, (self.P + 255) // 256, 4, device=self.dev)
+        _C.call("gq_surface_patches", _C.f32(self.surf), ctypes.c_int64(self.n_obj), ctypes.c_int64(self.P), _C.f32(self.patch),
+                _C.stream_ptr())
         # link-driven penetration query through a coarse grid over the objects' surface points (0 = the point-driven one)
         self.grid = None
         if self.penetration_only == 1 and point_grid and self.P <= 4096:
@@ -147,6 +151,7 @@ class GraspStepper:
                                                       self.terms_new[2].data_ptr())
         pd.span, pd.span_acc = self._span.data_ptr(), self._span_acc.data_ptr()
         pd.grid = self.grid.handle if self.grid is not None else None
+        pd.patch_spheres = self.patch.data_ptr()
         if self.S > 0:  # sphere centres + self penetration as a third role of the second fused launch
             pd.hand, pd.w_spen = self.hand.handle, float(self.w["E_spen"])
             pd.e_spen, pd.g_sphere_centers, pd.sphere_centers = (self.terms_new[3].data_ptr(), self.g_sph_w.data_ptr(),
@@ -230,7 +235,7 @@ class GraspStepper:
             _C.call("gq_hand_pen_forward", self.hand.links.handle, _C.f32(self.surf), self.n_obj, self.P, self.be,
                     _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T), int(self.penetration_only),
                     _C.f32(self.pen_dis), _C.i32(self.pen_link), _C.f32(self.pen_gvec),
-                    _C.ptr(self.pen_ws), self.pen_nb, timer, _C.ptr(self._span), st)
+                    _C.ptr(self.pen_ws), self.pen_nb, timer, _C.ptr(self._span), _C.f32(self.patch), st)
         _C.call("gq_hand_pen_backward", self.L, _C.f32(self.surf), self.n_obj, self.P, self.be, _C.f32(pose), self.D,
                 _C.f32(self.Rg), None, _C.i32(self.pen_link), _C.f32(self.pen_gvec), _C.f32(self.wrench), _C.f32(self.gRt),
                 _C.f32(self.pen_dis), float(self.w["E_pen"]), _C.f32(self.terms_new[2]), _C.ptr(self._span),

@@ -147,6 +147,7 @@ typedef struct gqPenStepDesc {
    * centres of link_T), so that gq_fk_forward can be called without spheres; hand == NULL: absent               */
   const gqHand* hand; float w_spen; float* e_spen; float* g_sphere_centers; float* sphere_centers /* or NULL */;
   const gqPointGrid* grid;                      /* optional: the query role runs link-driven (gq_hand_pen_forward_cells) */
+  const float* patch_spheres;                   /* optional: gq_surface_patches (see gq_hand_pen_forward) */
 } gqPenStepDesc;
 int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream);
 
@@ -283,7 +284,12 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points /* (
                         void* workspace /* NULL, or gq_hand_pen_workspace_bytes (ZEROED before first use): load-balanced path */,
                         size_t workspace_bytes, void* timer /* gqTimer or NULL */,
                         uint64_t* span /* NULL, or {min start, max end} in 100 MHz device ticks, pre-set to {~0, 0} */,
+                        const float* patch_spheres /* NULL, or gq_surface_patches of surface_points: lets every block of
+                                                      the penetration_only = 1 query drop the links out of reach first */,
                         void* stream);
+/* Bounding sphere (centre xyz, radius) of every 256-point slice of every object's surface points, (n_obj, ceil(P/256), 4);
+ * set-up time.  Surface points in Morton order (graspqp_amd.utils.meshes.surface_points) give compact slices.        */
+int gq_surface_patches(const float* surface_points, int64_t n_obj, int64_t n_surface, float* patch_spheres, void* stream);
 int gq_hand_pen_workspace_bytes(int64_t batch, int64_t n_surface, int n_links, size_t* bytes);
 /* The same penetration-only query (penetration_only = 1: dis exact where > 0, -1e30 elsewhere; link / gvec written only
  * where dis > 0) driven by the LINKS: a coarse uniform grid over every object's surface points (gqPointGrid, set-up

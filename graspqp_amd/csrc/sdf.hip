@@ -24,7 +24,14 @@ __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t*
 #include "sdf_dev.h"
 
 __global__ __launch_bounds__(256, 4) void gq_sdf_wave_kernel(GqWaveArgs g) {  // <= 128 VGPRs: 4 wavefronts per SIMD
-  const int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
+  int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
+  if (g.xcd_meshes) {  // block -> (XCD slot, mesh of that slot, block inside the mesh); see GqWaveArgs
+    const int b = (int)blockIdx.x, x = b & 7, i = b >> 3;
+    const int mesh = x + 8 * (i / g.blocks_per_mesh);
+    const int64_t in_mesh = (int64_t)(i % g.blocks_per_mesh) * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
+    if (mesh >= g.n_mesh || in_mesh >= g.queries_per_mesh) return;
+    q = (int64_t)mesh * g.queries_per_mesh + in_mesh;
+  }
   if (q >= g.N) return;
   const int lane = gq_lane();
   const GqSdfPre pre = gq_sdf_wave_prefetch(g, q, lane);
@@ -513,6 +520,7 @@ static void gq_box_of(const float* fv, const int32_t* perm, int64_t a, int64_t b
 }
 
 static unsigned long long* gq_pen_dbg_ = nullptr;
+static int gq_sdf_plain_mapping_ = 0;  // gq_debug_set_sdf_mapping(1): A/B switch for the XCD-aware query placement
 
 // Bound of a 64-face cluster: an oriented box, 16 floats = [centre.xyz, h_u][u.xyz, h_v][v.xyz, h_n][n.xyz, 0].
 // n = area-weighted mean normal of the patch, u = principal direction of its vertices in the plane orthogonal to n,
@@ -627,6 +635,11 @@ int gq_sdf_wave_args_(const gqMeshSet* ms, int64_t n_points, int64_t queries_per
 extern "C" {
 
 // diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
+int gq_debug_set_sdf_mapping(int plain) {
+  gq_sdf_plain_mapping_ = plain;
+  return GQ_OK;
+}
+
 int gq_debug_set_pen_counters(uint64_t* counters) {
   gq_pen_dbg_ = (unsigned long long*)counters;
   return GQ_OK;
@@ -846,7 +859,14 @@ int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_p
   int rc = gq_sdf_wave_args_(ms, n_points, queries_per_mesh, dist_sq, sign, normal, closest, &w);
   if (rc) return rc;
   w.points = points;
-  hipLaunchKernelGGL(gq_sdf_wave_kernel, dim3((unsigned)((n_points + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w);
+  unsigned blocks = (unsigned)((n_points + 3) / 4);
+  if (ms->n_mesh >= 8 && !gq_sdf_plain_mapping_) {  // several meshes: keep each mesh's queries on one XCD (its L2)
+    w.n_mesh = ms->n_mesh;
+    w.xcd_meshes = (ms->n_mesh + 7) / 8;
+    w.blocks_per_mesh = (int)((queries_per_mesh + 3) / 4);
+    blocks = (unsigned)(8 * w.xcd_meshes * w.blocks_per_mesh);
+  }
+  hipLaunchKernelGGL(gq_sdf_wave_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

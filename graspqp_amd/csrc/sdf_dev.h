@@ -17,6 +17,11 @@ struct GqWaveArgs {
   const int32_t* cl_off;   // (n_mesh+1) first 64-cluster of each mesh
   int single_F;
   int64_t queries_per_mesh;
+  // XCD-aware placement (mesh sets with several meshes): blocks b and b + 8 share an XCD (round-robin dispatch), so block
+  // b serves mesh (b % 8) + 8 j only -- every XCD's L2 then holds its own meshes instead of all of them.
+  int xcd_meshes;       // 0: plain mapping; else ceil(n_mesh / 8) = meshes per XCD
+  int blocks_per_mesh;  // ceil(queries_per_mesh / wavefronts per block)
+  int n_mesh;
   unsigned long long* dbg;  // diagnostics (gq_debug_set_pen_counters): [0] += cluster visits, [1] += queries
   float* dist_sq;
   int32_t* sign;

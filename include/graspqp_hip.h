@@ -308,6 +308,9 @@ int gq_hand_pen_forward_cells(const gqMeshSet* links, const gqPointGrid* grid, c
  * block's LDS lists were full, [7] blocks; gq_sdf_forward_meshset adds [0] 64-face cluster visits, [1] queries, sets
  * [2] = max visits of a query, adds [3] queries with > 16 visits.  Not read by the fused launches.                  */
 int gq_debug_set_pen_counters(uint64_t* counters /* device, 8 words, or NULL */);
+/* A/B switch: 1 = plain block -> query mapping in gq_sdf_forward_meshset; 0 (default) = XCD-aware (with >= 8 meshes the
+ * queries of mesh m run on the blocks b with b % 8 == m % 8, i.e. on one XCD, so each L2 holds only its own meshes). */
+int gq_debug_set_sdf_mapping(int plain);
 /* grad_dis (B,P) = upstream d E / d dis.  grad_dis == NULL selects the fused E_pen form: the weights are
  * w_pen * [dis > 0] and e_pen (B) = sum_j relu(dis_j) is written as well (core/energy.py:59-61).
  * span / span_acc (optional): the 64 x {min start, max end} shards filled by gq_hand_pen_forward are folded into

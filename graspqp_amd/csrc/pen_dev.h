@@ -136,32 +136,43 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
   const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
-  if (tid < g.L) {
+  for (int i = tid; i < g.L * 24; i += 256) {  // link transforms / boxes: independent loads, one round trip
+    const int l = i / 24, k = i % 24;
+    float v = 0.0f;
+    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
+    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
+    else if (k == 20) v = g.occ_invz[l];
+    s_link[i] = v;
+  }
+  float4 pslice = make_float4(0, 0, 0, -1.0f);
+  if (g.patch && tid < g.L) pslice = *reinterpret_cast<const float4*>(g.patch + ((size_t)obj * ((g.P + 255) / 256) + bx) * 4);
+  const bool has_faces = tid < g.L && g.off[tid + 1] > g.off[tid];
+  if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
+  s_pkey[tid] = 0ull;
+  __syncthreads();
+  if (tid < g.L) {  // bounding sphere of every link box in the hand frame + which links can reach this block's slice at all
     const int l = tid;
-    const float* T = g.link_T + ((size_t)row * g.L + l) * 12;
-    const float* bb = g.aabb + l * 8;
+    const float* T = s_link + l * 24;
+    const float* bb = T + 12;
     const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
     const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
     const gq3 sc = gq_mk(T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3], T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7],
                          T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11]);
-    const float r2 = (g.off[l + 1] > g.off[l]) ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
+    const float r2 = has_faces ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
     s_sph[l * 4 + 0] = sc.x;
     s_sph[l * 4 + 1] = sc.y;
     s_sph[l * 4 + 2] = sc.z;
     s_sph[l * 4 + 3] = r2;
     bool reach = r2 >= 0.0f;
-    if (g.patch && reach) {  // can the link's bounding sphere reach the bounding sphere of this block's slice at all?
-      const float* ps = g.patch + ((size_t)obj * ((g.P + 255) / 256) + bx) * 4;
-      const gq3 pc = gq_mtv(R, gq_mk(ps[0] - hp[0], ps[1] - hp[1], ps[2] - hp[2]));  // slice centre in the hand frame
+    if (g.patch && reach) {
+      const gq3 pc = gq_mtv(R, gq_mk(pslice.x - hp[0], pslice.y - hp[1], pslice.z - hp[2]));  // slice centre, hand frame
       const gq3 d = pc - sc;
-      const float rr = ps[3] + sqrtf(r2);
+      const float rr = pslice.w + sqrtf(r2);
       reach = gq_dot(d, d) <= rr * rr * 1.0001f + 1e-12f;
     }
     const unsigned long long m = __ballot(reach);  // links 0 .. L-1 sit in wavefront 0 (L <= 64)
     if (tid == 0) *reinterpret_cast<unsigned long long*>(s_cnt + 4) = m;
   }
-  if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
-  s_pkey[tid] = 0ull;
   __syncthreads();
   const unsigned long long lmask = *reinterpret_cast<const unsigned long long*>(s_cnt + 4);
   if (lmask == 0ull) {  // no link can touch this slice: nothing penetrates
@@ -170,16 +181,6 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     if (g.span && tid == 0) gq_span_close(g.span, block_id);
     return;
   }
-  for (int i = tid; i < g.L * 24; i += 256) {  // transforms / boxes of the links that can (the others are never read)
-    const int l = i / 24, k = i % 24;
-    if (!((lmask >> l) & 1ull)) continue;
-    float v = 0.0f;
-    if (k < 12) v = g.link_T[((size_t)row * g.L + l) * 12 + k];
-    else if (k < 20) v = g.aabb[l * 8 + (k - 12)];
-    else if (k == 20) v = g.occ_invz[l];
-    s_link[i] = v;
-  }
-  __syncthreads();
   // ---- A: scan -------------------------------------------------------------------------------------------------
   float in_dis = 0.0f;  // result of entries this thread had to rank inline (capacity overflow)
   int in_link = -1;
@@ -199,8 +200,12 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     if (!(near && gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
     const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
     const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
-    if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
-    if (!EVAL) continue;
+    if (!EVAL) {
+      if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
+      continue;
+    }
+    // (no look-up of the occupancy bit first: a voxel that is not occupied has an empty candidate list -- one dependent
+    // round trip less)
     const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
     const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
     if (len == 0u) continue;

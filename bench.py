@@ -47,9 +47,11 @@ def parse_args(argv=None):
     ap.add_argument("--n_cone_vecs", type=int, default=4, help="friction-cone edges per contact (BASELINE configs[4] uses 8)")
     ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
     ap.add_argument("--hand", default="allegro")
-    ap.add_argument("--fork", type=int, default=0, help="1: the two branches of the evaluation as parallel hipGraph branches (A/B)")
+    ap.add_argument("--fork", type=int, default=-1, help="1: every role its own launch, the two branches of the evaluation as "
+                    "parallel hipGraph branches; -1 (default): follow the batch size (from 512 rows on)")
     ap.add_argument("--graph_iters", type=int, default=8, help="MALA* iterations captured per hipGraph (reduced to a divisor of --steps)")
-    ap.add_argument("--fused", type=int, default=1, help="1: force-closure and penetration branches share two launches (default)")
+    ap.add_argument("--fused", type=int, default=-1, help="1: force-closure and penetration branches share two launches; "
+                    "-1 (default): follow the batch size (below 512 rows)")
     ap.add_argument("--graph", type=int, default=1, help="replay the iteration from hipGraphs (1, default) or launch eagerly (0)")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL, default) | gloo: rehearsal of the multi-process path "
                     "on fewer GPUs than ranks (ranks share devices round-robin; collectives go through host memory)")
@@ -243,7 +245,8 @@ def rank_main(args):
     g_iters = 0
     if args.graph:
         g_iters = max(d for d in (1, 2, 4, 8, 16, 32, 64) if d <= max(1, args.graph_iters) and args.steps % d == 0)
-        st.capture(fork=bool(args.fork), fused=bool(args.fused), iters=g_iters)
+        st.capture(fork=None if args.fork < 0 else bool(args.fork), fused=None if args.fused < 0 else bool(args.fused),
+                   iters=g_iters)
     for _ in range(args.warmup):
         st.step()
     st.realign_draws()  # a warm-up that is not a multiple of the graph length ends with eager iterations (untimed);
@@ -281,7 +284,7 @@ def rank_main(args):
     # (2) the fused launch sequence issued eagerly, a torch event pair around every C-ABI call (they run on torch's
     # current stream): live duration of each launch group
     group_ms = {}
-    if args.fused and st.penetration_only == 1:
+    if args.fused != 0 and st.penetration_only == 1:
         names = ["fk_forward(+propose" + ("+object SDF)" if B <= 512 else ")"), "object_sdf", "stage_a+stop+stage_b",
                  "fk_backward(+energies+accept)"]
         acc = {k: [] for k in names}
@@ -407,7 +410,7 @@ def rank_main(args):
                                    + (" (BASELINE configs[1])" if is_cfg2 else ""),
                        "rows_per_gpu": B, "hip_graph": bool(args.graph), "iterations_per_graph": g_iters,
                        "eager_iterations_in_timed_region": 0,
-                       "branches": ("one grid" if args.fused else "graph branches" if args.fork else "serial") if args.graph else "eager"},
+                       "branches": getattr(st, "graph_mode", "eager") if args.graph else "eager"},
             "timing": {"windows": len(window_s), "window_ms": [w * 1e3 for w in window_s], "statistic": "median",
                        "host_enqueue_ms_per_step": float(np.median(enq_s)) / args.steps * 1e3},
             "mean_energy": float(st.energy.mean()), "accept_rate_last": float(st.accept.float().mean()),

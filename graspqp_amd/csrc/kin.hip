@@ -33,8 +33,19 @@ struct GqFkArgs {
 // One wavefront does the kinematics of the row (the barriers below are wavefront-level: blocks of this kernel are either
 // a single wavefront, or -- with the object SDF attached -- wavefront 0 plus query wavefronts that wait at the one
 // block barrier further down).
+// Column means of clip(grad)^2 over ALL rows (optimizer.py:231) without a launch of their own: every block computes them
+// redundantly (B <= 512 rows x D floats, L2 hits) with its query wavefronts, which have nothing to do before the
+// kinematics are through.  Lane groups k = (wave - 1) * G + grp (G = 64 / D groups of D lanes per wavefront) take the
+// units k, k + K, ... of the canonical order (loop_dev.h); wavefront 0 adds the 16 partial sums in unit order.
+__device__ __forceinline__ void gq_colsq_partial(const GqProposeArgs& p, int wv, int nw, int lane, float* sPart) {
+  const int D = p.D, G = GQ_WAVE / D, grp = lane / D, col = lane % D, K = (nw - 1) * G;
+  if (grp < G)
+    for (int u = (wv - 1) * G + grp; u < GQ_COLSQ_UNITS; u += K) sPart[u * D + col] = gq_colsq_unit(p.grad, p.B, D, p.clip, u, col);
+}
+
 __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, int lane, float* sW, float* sT, float* sC,
-                                                  unsigned long long* sKey, float* sRad, float* sCP, float* sPose) {
+                                                  unsigned long long* sKey, float* sRad, float* sCP, float* sPose,
+                                                  const float* sPart = nullptr) {
   const gqHand& h = g.h;
   // The constant hand tables this lane needs (its joint node, its link, its first sphere, its sphere group) are loaded
   // BEFORE anything else: a single wavefront per row hides no latency, and the barriers / fences below would otherwise
@@ -58,7 +69,13 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
   int64_t my_idx = 0;
   const bool z_here = !sCP || (int)blockDim.x < 2 * GQ_WAVE;  // otherwise wavefront 1 computes the z-score while it waits
   if (g.has_propose) {  // the proposal of this row, then its forward kinematics: pose and indices are handed over in
-    gq_propose_body(g.pr, row, lane, sPose, &my_idx, z_here, slot_now);  // LDS / registers, no wait for its own stores
+    float g2v[2] = {0.0f, 0.0f};
+    if (sPart) {  // block barrier A: the query wavefronts have left their partial column sums
+      __syncthreads();
+      if (lane < g.pr.D) g2v[0] = gq_colsq_finish(sPart, g.pr.B, g.pr.D, lane);
+      if (row == 0 && lane < g.pr.D) const_cast<float*>(g.pr.g2)[lane] = g2v[0];  // kept observable (g2_scratch)
+    }
+    gq_propose_body(g.pr, row, lane, sPose, &my_idx, z_here, slot_now, sPart ? g2v : nullptr);  // LDS / registers, no wait for its own stores
     gq_wave_sync();
     hp = sPose;
     if (g.n > GQ_WAVE) __threadfence_block();  // contacts beyond the first 64 re-read their indices from memory
@@ -152,8 +169,10 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ float sRad[256];
   __shared__ float sCP[GQ_WAVE * 3];        // world contact points handed to the query wavefronts
   __shared__ float sPose[128];              // the proposed pose (head of the row's kinematics)
+  __shared__ float sPart[GQ_COLSQ_UNITS * GQ_WAVE];  // partial column sums of the squared gradient (g2_inline)
   const int row = blockIdx.x, lane = gq_lane(), wv = (int)threadIdx.x / GQ_WAVE;
   const int nw = (int)blockDim.x / GQ_WAVE;
+  const bool g2_here = g.has_propose && g.pr.g2_inline;
   if (!g.has_sdf) {
     gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, nullptr, sPose);
     return;
@@ -161,13 +180,17 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   // Two code paths so that the prefetched boxes are not live across the kinematics: wavefront 0 does the kinematics,
   // the others fetch mesh offsets and cluster boxes of their first query meanwhile; everybody meets at ONE barrier.
   if (wv == 0) {
-    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, sCP, sPose);
+    gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, sCP, sPose, g2_here ? sPart : nullptr);
     __syncthreads();
     for (int c = 0; c < g.n; c += nw) {
       const GqSdfPre pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + c, lane);
       gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + c, gq_fk_contact_point(g, sCP, row, c), lane, pre);
     }
   } else {
+    if (g2_here) {
+      gq_colsq_partial(g.pr, wv, nw, lane, sPart);
+      __syncthreads();  // barrier A (wavefront 0 waits in gq_fk_forward_row)
+    }
     GqSdfPre pre;
     if (wv < g.n) pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + wv, lane);
     // the z-score of the old energies (only the accept step needs it) is computed by wavefront 1 while it waits
@@ -715,10 +738,6 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
     a.pr.slot_ctr = p.slot_ctr;
     a.pr.slots = p.slots;
   }
-  if (propose) {  // the RMS mean couples all rows (optimizer.py:231): its own small launch, then everything per row
-    int rc = gq_colsq_launch_(propose->grad, (int)batch, a.D, propose->clip_grad, propose->g2_scratch, stream);
-    if (rc) return rc;
-  }
   int nw = 1;
   if (sdf) {  // the contact queries of a row are answered by the row's block: up to 12 query wavefronts
     GQ_REQUIRE(n_contact > 0 && contact_points, "fk_forward: gqSdfDesc needs contact points");
@@ -728,6 +747,16 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
     a.has_sdf = 1;
     const int rounds = (n_contact + 11) / 12;
     nw = (n_contact + rounds - 1) / rounds;
+  }
+  if (propose) {
+    // the RMS mean couples all rows (optimizer.py:231).  Small batches with query wavefronts in the block: every block
+    // reduces it redundantly while its kinematics wavefront fetches the hand tables (no launch); otherwise a small
+    // launch of its own, then everything per row
+    a.pr.g2_inline = (nw >= 3 && a.D <= GQ_WAVE && batch <= 512) ? 1 : 0;
+    if (!a.pr.g2_inline) {
+      int rc = gq_colsq_launch_(propose->grad, (int)batch, a.D, propose->clip_grad, propose->g2_scratch, stream);
+      if (rc) return rc;
+    }
   }
   hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE * nw), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();

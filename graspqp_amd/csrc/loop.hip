@@ -164,6 +164,16 @@ __global__ __launch_bounds__(256) void gq_colsq_mean_kernel(const float* __restr
   if (tid == 0) g2[col] = red[0] / (float)B;
 }
 
+// same means for batches <= 512 rows and D <= 64 in the canonical order of loop_dev.h: wavefront u = unit u
+__global__ __launch_bounds__(GQ_COLSQ_UNITS * GQ_WAVE) void gq_colsq_units_kernel(const float* __restrict__ grad, int B, int D,
+                                                                              int clip, float* __restrict__ g2) {
+  __shared__ float sPart[GQ_COLSQ_UNITS * GQ_WAVE];
+  const int lane = gq_lane(), unit = (int)threadIdx.x / GQ_WAVE;
+  if (lane < D) sPart[unit * D + lane] = gq_colsq_unit(grad, B, D, clip, unit, lane);
+  __syncthreads();
+  if (unit == 0 && lane < D) g2[lane] = gq_colsq_finish(sPart, B, D, lane);
+}
+
 // z = (E - mean_obj) / std_obj (unbiased), one block per object
 __global__ __launch_bounds__(256) void gq_zscore_kernel(const float* __restrict__ energy, int batch_each,
                                                         float* __restrict__ z) {
@@ -207,7 +217,10 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_mala_accept_kernel(GqAcceptArgs g)
 }
 
 int gq_colsq_launch_(const float* grad, int B, int D, int clip, float* g2, void* stream) {
-  hipLaunchKernelGGL(gq_colsq_mean_kernel, dim3((unsigned)D), dim3(256), 0, (hipStream_t)stream, grad, B, D, clip, g2);
+  if (B <= 512 && D <= GQ_WAVE)
+    hipLaunchKernelGGL(gq_colsq_units_kernel, dim3(1), dim3(GQ_COLSQ_UNITS * GQ_WAVE), 0, (hipStream_t)stream, grad, B, D, clip, g2);
+  else
+    hipLaunchKernelGGL(gq_colsq_mean_kernel, dim3((unsigned)D), dim3(256), 0, (hipStream_t)stream, grad, B, D, clip, g2);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }
@@ -314,9 +327,10 @@ int gq_mala_propose(const float* hand_pose, const float* grad, const int64_t* co
                  g2_scratch && batch > 0 && pose_dim > 9 && pose_dim <= 128 && n_contact > 0 && stepsize_period > 0,
              "mala_propose: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gq_colsq_mean_kernel, dim3((unsigned)pose_dim), dim3(256), 0, st, grad, (int)batch, pose_dim,
-                     clip_grad, g2_scratch);
-  GQ_LAUNCH_CHECK();
+  {
+    const int rc = gq_colsq_launch_(grad, (int)batch, pose_dim, clip_grad, g2_scratch, stream);
+    if (rc) return rc;
+  }
   GqProposeArgs a{};
   a.hand_pose = hand_pose;
   a.grad = grad;

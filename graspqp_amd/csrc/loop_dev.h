@@ -25,6 +25,7 @@ struct GqProposeArgs {
   // slot_ctr[0] selects the current one
   int* slot_ctr;
   int slots;
+  int g2_inline;  // gq_fk_forward only: the block's query wavefronts reduce the column means themselves (no launch)
 };
 
 // one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
@@ -33,10 +34,16 @@ struct GqProposeArgs {
 // with_z = false leaves the z-score to a separate gq_zscore_row call (e.g. by another, idle wavefront).
 __device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane);
 __device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane, float* s_pose = nullptr,
-                                                int64_t* my_idx = nullptr, bool with_z = true, int slot_now = -1) {
+                                                int64_t* my_idx = nullptr, bool with_z = true, int slot_now = -1,
+                                                const float* g2_regs = nullptr) {
   float g2[2];
-  g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
-  g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
+  if (g2_regs) {  // the caller has the column means of this lane's elements in registers already
+    g2[0] = g2_regs[0];
+    g2[1] = g2_regs[1];
+  } else {
+    g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
+    g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
+  }
   // slot_now >= 0: the caller has already read slot_ctr[0] (early, so that the dependent loads below need not wait for it)
   const int ctr = g.slot_ctr ? (slot_now >= 0 ? slot_now : g.slot_ctr[0]) : 0;
   const size_t draw0 = g.slot_ctr ? (size_t)(ctr % g.slots) * g.B * g.n : 0;
@@ -99,6 +106,28 @@ __device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, i
     const float sd = sqrtf(gq_dpp_sum(acc) / (float)(g.batch_each - 1));
     if (lane == 0) g.z_out[row] = (g.energy[row] - mean) / sd;
   }
+}
+
+// Column means of clip(grad)^2 over all rows (optimizer.py:231) for batches <= 512 rows and D <= 64, in ONE canonical
+// order so that the stand-alone launch (loop.hip) and the query wavefronts of gq_fk_forward (kin.hip) give the same bits:
+// unit u < 16 sums the rows u, u + 16, ... of every column (lane = column) with fma(v, v, acc); the 16 partial sums are
+// added in unit order and divided by the number of rows.
+#define GQ_COLSQ_UNITS 16
+__device__ __forceinline__ float gq_colsq_unit(const float* __restrict__ grad, int B, int D, int clip, int unit, int col) {
+  float acc = 0.0f;
+#pragma unroll 4
+  for (int r = unit; r < B; r += GQ_COLSQ_UNITS) {
+    float v = grad[(size_t)r * D + col];
+    if (clip) v = (v != v) ? 0.0f : fminf(fmaxf(v, -100.0f), 100.0f);  // NaN -> 0 first: fmaxf(NaN, -100) would be -100
+    acc = fmaf(v, v, acc);
+  }
+  return acc;
+}
+// sPart: [GQ_COLSQ_UNITS][D] partial sums
+__device__ __forceinline__ float gq_colsq_finish(const float* sPart, int B, int D, int col) {
+  float t = 0.0f;
+  for (int u = 0; u < GQ_COLSQ_UNITS; ++u) t += sPart[u * D + col];
+  return t / (float)B;
 }
 
 struct GqAcceptArgs {

@@ -504,11 +504,14 @@ class GraspStepper:
                 self._iteration(st, fused=self._can_fuse)
             self._graph_pending = 0
 
-    def capture(self, fork=False, fused=True, iters=1):
+    def capture(self, fork=None, fused=None, iters=1):
         """Capture one iteration into a hipGraph: FK forward (with the proposal as its head and the self-penetration
         term), object SDF of the contacts, the two stage launches that hold the force-closure and the penetration
-        branch side by side (``fused``; ``fork`` = the branches as parallel graph branches instead, for A/B runs), FK
-        backward (with the energies and the accept step as its tail) -- five launches, no host involvement.  ``iters``
+        branch side by side (``fused``), FK backward (with the energies and the accept step as its tail) -- five
+        launches, no host involvement.  ``fork`` = every role its own launch, the two branches as parallel graph
+        branches: per-role occupancy instead of one register budget for both roles.  Left at None the mode follows the
+        batch: one grid below 512 rows (latency: 3.03 vs 2.53 M evals/s at 256 rows), graph branches from 512 rows on
+        (throughput: 3.9 vs 3.6 M at 512, 7.2 vs 6.1 M at 2048, 7.9 vs 6.6 M at 4096; tools/ab_fork.sh).  ``iters``
         > 1 captures that many consecutive iterations in one graph (every kernel finds its random draws through the
         device-side slot counter), which removes the graph-launch gap between iterations; ``step`` then replays once
         per ``iters`` calls and ``flush`` runs a remainder.  The state is saved and restored around the warm-up +
@@ -517,8 +520,13 @@ class GraspStepper:
                 self._span_acc, self._slot_ctr)
         saved = [t.clone() for t in keep]
         rng = (self.gen.get_state(), self._draw_pos)
+        if fused is None:
+            fused = self.B < 512 if fork is None else not fork
+        if fork is None:
+            fork = not fused
         fused = fused and self._can_fuse
         fork = fork and not fused
+        self.graph_mode = "one grid" if fused else "graph branches" if fork else "serial"
         if fork and self._side is None:
             self._side = torch.cuda.Stream()
         s = torch.cuda.Stream()

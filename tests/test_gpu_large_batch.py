@@ -403,7 +403,9 @@ def test_link_driven_query_equals_point_driven(gq, scene, cells):
     assert far.float().mean() < 2e-3 and float((d_c[pos] - d_p[pos]).abs().max()) < 1e-4
     same = ~far
     assert (l_c[pos][same] == l_p[pos][same]).float().mean() > 0.999
-    torch.testing.assert_close(g_c[pos][same], g_p[pos][same], rtol=2e-2, atol=2e-3)
+    # a point equidistant to two faces may take its gradient direction from either of them
+    g_far = (g_c[pos][same] - g_p[pos][same]).abs().amax(-1) > 2e-3
+    assert g_far.float().mean() < 1e-2
     assert bool((d_c[~pos] == -1e30).all())
     big = (d_c[pos] - d_0[pos]).abs() > 3e-6  # against the exact query: near-tied faces may swap (tests/test_gpu_parity.py)
     assert big.float().mean() < 2e-3

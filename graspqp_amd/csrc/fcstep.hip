@@ -19,6 +19,17 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_head_kernel(GqFcStepArgs g) {
   extern __shared__ float gq_sh[];
   gq_fc_head_body<NC>(g, (int)blockIdx.x, gq_sh);
 }
+// large batches: GQ_HEAD_ROWS rows per block (one wavefront each) + the stop rule as epilogue of the last block
+template <int NC>
+__global__ __launch_bounds__(GQ_HEAD_ROWS* GQ_WAVE) void gq_fc_head_stop_kernel(GqFcStepArgs g) {
+  extern __shared__ float gq_sh[];
+  const int blk = (int)blockIdx.x, wv = (int)threadIdx.x / GQ_WAVE, row = blk * GQ_HEAD_ROWS + wv;
+  if (row >= g.B) return;
+  float hr, hm;
+  gq_fc_head_body<NC>(g, row, gq_sh + wv * g.n * 6, &hr, &hm);
+  const int nrow = g.B - blk * GQ_HEAD_ROWS < GQ_HEAD_ROWS ? g.B - blk * GQ_HEAD_ROWS : GQ_HEAD_ROWS;
+  gq_fc_head_epilogue(g, blk, wv, nrow, hr, hm, reinterpret_cast<unsigned*>(gq_sh + GQ_HEAD_ROWS * g.n * 6));
+}
 template <int NC, int RPL>
 __global__ __launch_bounds__(GQ_WAVE) void gq_fc_tail_kernel(GqFcStepArgs g) {
   extern __shared__ float gq_sh[];
@@ -29,7 +40,8 @@ extern "C" {
 
 // Fused force-closure step of the MALA* iteration: contact terms + E_fc forward + backward with constant upstream
 // weights (w_dis on E_dis, w_fc on E_fc).  Same workspace as gq_fc_forward (gq_fc_workspace_bytes); gq_fc_peek works
-// on it afterwards (F, x, val, svd).
+// on it afterwards (F, x, val, svd).  The workspace must be zero-filled ONCE after it is allocated (a block counter of
+// the head launch lives in it and returns to zero by itself).
 int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, const float* closest,
                const float* contact_pts, const float* hand_normals, const float* cog, int64_t batch, int n_contact,
                int n_cone, float friction, float torque_weight, float max_limit, float svd_gain, float values_gain,
@@ -47,11 +59,19 @@ int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, 
   const dim3 grid((unsigned)batch), block(GQ_WAVE);
   const size_t lds_head = (size_t)n_contact * 6 * sizeof(float), lds_tail = (size_t)nz * 3 * sizeof(float);
   const bool two = nz > GQ_WAVE;
-  if (two) hipLaunchKernelGGL((gq_fc_head_kernel<2>), grid, block, lds_head, st, a);
-  else hipLaunchKernelGGL((gq_fc_head_kernel<1>), grid, block, lds_head, st, a);
+  if (a.agg) {  // the stop rule rides in the head launch (see gq_fc_head_epilogue)
+    const dim3 hgrid((unsigned)a.head_blocks), hblock(GQ_HEAD_ROWS * GQ_WAVE);
+    const size_t lds = GQ_HEAD_ROWS * lds_head + GQ_HEAD_LDS_WORDS * sizeof(unsigned);
+    if (two) hipLaunchKernelGGL((gq_fc_head_stop_kernel<2>), hgrid, hblock, lds, st, a);
+    else hipLaunchKernelGGL((gq_fc_head_stop_kernel<1>), hgrid, hblock, lds, st, a);
+  } else if (two) {
+    hipLaunchKernelGGL((gq_fc_head_kernel<2>), grid, block, lds_head, st, a);
+  } else {
+    hipLaunchKernelGGL((gq_fc_head_kernel<1>), grid, block, lds_head, st, a);
+  }
   GQ_LAUNCH_CHECK();
   const bool fused_stop = batch <= 4 * GQ_WAVE && max_iter <= 16;
-  if (!fused_stop) {
+  if (!fused_stop && !a.agg) {
     rc = gq_qp_stop_launch_(a.resid, a.mu_tab, a.B, max_iter, eps, a.not_improved_lim, runmin, a.kstar, n_iter, stream);
     if (rc) return rc;
   }

@@ -27,11 +27,22 @@ struct GqFcStepArgs {
   float* svd;         // (B)
   float* x;           // (B,nz) best iterate (kept for gq_fc_peek)
   float* x_sum;       // (B,n) or null
+  // batches too large for the tail to replay the stop rule per row (gq_qp_stop_rows): the head blocks leave per-block
+  // aggregates and the block that finishes last applies qpth's rule to them (gq_fc_head_epilogue) -- no stop launch
+  unsigned* agg;      // (head_blocks, GQ_AGG_WORDS) or null
+  unsigned* head_ctr; // one word, zero between launches
+  int head_blocks;
 };
+#ifndef GQ_HEAD_ROWS
+#define GQ_HEAD_ROWS 4  // fc-head rows (wavefronts) per block
+#endif
+#define GQ_AGG_WORDS 36  // 16 x max of the running best residual | 16 x min of mu | improved-bit mask | 3 pad
+#define GQ_HEAD_LDS_WORDS (4 * GQ_AGG_WORDS)  // epilogue: the aggregates of the block's rows
 
 // one wavefront = one row; sh: n*6 floats of LDS (contact points, object normals)
 template <int NC>
-__device__ __forceinline__ void gq_fc_head_body(const GqFcStepArgs& g, int row, float* sh) {
+__device__ __forceinline__ void gq_fc_head_body(const GqFcStepArgs& g, int row, float* sh, float* hist_resid = nullptr,
+                                                float* hist_mu = nullptr) {
   const int lane = gq_lane();
   float* s_cp = sh;
   float* s_on = sh + g.n * 3;
@@ -94,7 +105,127 @@ __device__ __forceinline__ void gq_fc_head_body(const GqFcStepArgs& g, int row, 
   q.resid = g.resid;
   q.mu = g.mu_tab;
   q.snap = g.snap;
-  gq_qp_lr_iterate<6, NC>(q, row, lane, S, live, p, hu, hl);
+  gq_qp_lr_iterate<6, NC>(q, row, lane, S, live, p, hu, hl, hist_resid, hist_mu);
+}
+
+// qpth's batch-global stop rule without a launch of its own, for any batch size (max_iter <= 16).  Called by every
+// wavefront of a head block after its row (lane it holds the row's residual / mu of iteration it):
+//   1. each wavefront replays its row: running best residual per iteration, "improved in iteration it" bits;
+//   2. wavefront 0 folds the block's rows (max of the running bests, min of mu -- NaN-propagating like torch -- and the
+//      OR of the bits) into one 33-word record in global memory, publishes it and counts the block;
+//   3. the block that finishes LAST folds all records and applies the sequential rule (notImproved == lim | max best <
+//      eps | min mu > 1e32) -> kstar / n_iter.  The counter wraps to zero by itself (atomicInc), so the workspace only
+//      has to be zero once, when it is allocated.
+// sh: GQ_HEAD_LDS_WORDS words of LDS; nrow: rows (wavefronts) of this block that are alive.
+__device__ __forceinline__ void gq_fc_head_epilogue(const GqFcStepArgs& g, int blk, int wv, int nrow, float hist_resid,
+                                                    float hist_mu, unsigned* sh) {
+  const int lane = gq_lane();
+  float bst = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist_resid), 0));
+  float my_bst = bst;
+  unsigned any = 0u;
+#pragma unroll
+  for (int it = 1; it < 16; ++it) {
+    const float rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hist_resid), it));
+    if (it < g.max_iter && rs < bst) {  // wave-uniform; false for NaN on either side, like the reference's comparison
+      bst = rs;
+      any |= 1u << it;
+    }
+    if (lane == it) my_bst = bst;
+  }
+  if (lane < 16) {
+    sh[wv * GQ_AGG_WORDS + lane] = __float_as_uint(my_bst);
+    sh[wv * GQ_AGG_WORDS + 16 + lane] = __float_as_uint(hist_mu);
+  }
+  if (lane == 32) sh[wv * GQ_AGG_WORDS + 32] = any;
+  __syncthreads();
+  if (wv != 0) return;
+  unsigned word = 0u;
+  if (lane < 16) {
+    float v = -GQ_INF;
+    for (int r = 0; r < nrow; ++r) v = gq_nanmax(v, __uint_as_float(sh[r * GQ_AGG_WORDS + lane]));
+    word = __float_as_uint(v);
+  } else if (lane < 32) {
+    float v = GQ_INF;
+    for (int r = 0; r < nrow; ++r) v = gq_nanmin(v, __uint_as_float(sh[r * GQ_AGG_WORDS + lane]));
+    word = __float_as_uint(v);
+  } else if (lane == 32) {
+    for (int r = 0; r < nrow; ++r) word |= sh[r * GQ_AGG_WORDS + 32];
+  }
+  // The record goes out with agent-scope (write-through) stores and the counter is bumped once they are acknowledged.
+  // NOT a release fence: that would write back this XCD's whole L2, which is full of the iterate snapshots the rows
+  // have just stored (24 MB per launch at 2048 rows).
+  if (lane <= 32) __hip_atomic_store(&g.agg[(size_t)blk * GQ_AGG_WORDS + lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned old = 0u;
+  if (lane == 0) old = atomicInc(g.head_ctr, (unsigned)g.head_blocks - 1u);
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (unsigned)g.head_blocks - 1u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidate only: the other blocks' records come from memory
+  // fold all records: lane L takes the records L, L + 64, ... whole (nine 16-byte loads each, two records in flight)
+  float amx[16], amn[16];
+  unsigned abits = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    amx[i] = -GQ_INF;
+    amn[i] = GQ_INF;
+  }
+  const uint4* rec4 = reinterpret_cast<const uint4*>(g.agg);
+  for (int b0 = lane; b0 < g.head_blocks; b0 += 2 * GQ_WAVE) {
+    uint4 q[2][9];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int b = b0 + j * GQ_WAVE < g.head_blocks ? b0 + j * GQ_WAVE : b0;  // a duplicate record changes nothing
+#pragma unroll
+      for (int k = 0; k < 9; ++k) q[j][k] = rec4[(size_t)b * (GQ_AGG_WORDS / 4) + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        amx[4 * k + 0] = gq_nanmax(amx[4 * k + 0], __uint_as_float(q[j][k].x));
+        amx[4 * k + 1] = gq_nanmax(amx[4 * k + 1], __uint_as_float(q[j][k].y));
+        amx[4 * k + 2] = gq_nanmax(amx[4 * k + 2], __uint_as_float(q[j][k].z));
+        amx[4 * k + 3] = gq_nanmax(amx[4 * k + 3], __uint_as_float(q[j][k].w));
+        amn[4 * k + 0] = gq_nanmin(amn[4 * k + 0], __uint_as_float(q[j][4 + k].x));
+        amn[4 * k + 1] = gq_nanmin(amn[4 * k + 1], __uint_as_float(q[j][4 + k].y));
+        amn[4 * k + 2] = gq_nanmin(amn[4 * k + 2], __uint_as_float(q[j][4 + k].z));
+        amn[4 * k + 3] = gq_nanmin(amn[4 * k + 3], __uint_as_float(q[j][4 + k].w));
+      }
+      abits |= q[j][8].x;
+    }
+  }
+  // fold the 64 per-lane results with the DPP network (no LDS: a transpose buffer would cost every head block 8 KB)
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float mx = -gq_dpp_nanmin(-amx[i]);  // NaN-propagating max, wave-uniform
+    const float mn = gq_dpp_nanmin(amn[i]);
+    if (lane == i) acc = mx;
+    if (lane == 16 + i) acc = mn;
+  }
+  unsigned bits = abits;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bits |= (unsigned)__shfl_xor((int)bits, o, GQ_WAVE);
+  const unsigned anyb = (unsigned)__builtin_amdgcn_readlane((int)bits, 32);
+  int not_improved = 0, stop_at = g.max_iter - 1;
+  bool done = false;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const float bmx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), it));
+    const float bmn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16 + it));
+    if (it < g.max_iter && !done) {
+      not_improved = (it == 0) ? 0 : (((anyb >> it) & 1u) ? 0 : not_improved + 1);
+      if ((not_improved == g.not_improved_lim) || (bmx < g.eps) || (bmn > 1e32f)) {
+        stop_at = it;
+        done = true;
+      }
+    }
+  }
+  if (lane == 0) {
+    g.kstar[0] = stop_at;
+    g.kstar[1] = stop_at + 1;
+    if (g.n_iter) *g.n_iter = stop_at + 1;
+  }
 }
 
 // qpth's batch-global stop rule (qp.hip::gq_qp_stop_wave_kernel) evaluated by one wavefront from registers: lane l owns
@@ -347,7 +478,8 @@ __device__ __forceinline__ void gq_fc_tail_body(const GqFcStepArgs& g, int row, 
 
 // ---- host side: argument block of the fused step (parameters of gq_fc_step) ----------------------------------------
 int gq_qp_tables_(void* workspace, size_t workspace_bytes, int B, int nz, int max_iter, float** resid, float** mu,
-                  float** snap, float** runmin, int** kstar);
+                  float** snap, float** runmin, int** kstar, unsigned** agg);
+
 static inline int gq_fc_step_fill(const float* dist_sq, const int32_t* sign, const float* obj_dir, const float* closest,
                                   const float* contact_pts, const float* hand_normals, const float* cog, int64_t batch,
                                   int n_contact, int n_cone, float friction, float torque_weight, float max_limit,
@@ -368,8 +500,11 @@ static inline int gq_fc_step_fill(const float* dist_sq, const int32_t* sign, con
   GQ_REQUIRE(workspace_bytes >= need, "fc_step: workspace too small (%zu < %zu)", workspace_bytes, need);
   GqFcWs w = gq_fc_carve(workspace, (size_t)batch, (size_t)nz, workspace_bytes);
   GqFcStepArgs a{};
-  rc = gq_qp_tables_(w.qp, w.qp_bytes, (int)batch, nz, max_iter, &a.resid, &a.mu_tab, &a.snap, runmin, &a.kstar);
+  rc = gq_qp_tables_(w.qp, w.qp_bytes, (int)batch, nz, max_iter, &a.resid, &a.mu_tab, &a.snap, runmin, &a.kstar, &a.agg);
   if (rc) return rc;
+  a.head_ctr = reinterpret_cast<unsigned*>(a.kstar) + 8;
+  a.head_blocks = ((int)batch + GQ_HEAD_ROWS - 1) / GQ_HEAD_ROWS;
+  if (max_iter > 16 || batch <= 4 * GQ_WAVE) a.agg = nullptr;  // stop launch | replayed per row by the tail
   a.dist_sq = dist_sq;
   a.sign = sign;
   a.onrm = obj_dir;

@@ -110,18 +110,21 @@ __device__ __forceinline__ unsigned long long gq_rank_key(float d2, unsigned ori
   return ((unsigned long long)b << 32) | ((unsigned long long)(orig_local & 0xffffu) << 16) | (f_local & 0xffffu);
 }
 // LDS of one block (bytes): entries, entry keys, items (re-used for the finished entries), point keys, counters, links
-__host__ __device__ inline size_t gq_pen_grid_lds_bytes(int L) {
-  return (size_t)GQ_PG_ECAP * (sizeof(GqPgEntry) + 8) + (size_t)GQ_PG_ICAP * 4 + 256 * 8 + 32 + (size_t)L * 28 * 4;
+__host__ __device__ inline size_t gq_pen_grid_lds_bytes(int L, int ecap = GQ_PG_ECAP, int icap = GQ_PG_ICAP) {
+  return (size_t)ecap * (sizeof(GqPgEntry) + 8) + (size_t)icap * 4 + 256 * 8 + 32 + (size_t)L * 28 * 4;
 }
 // block = 256 threads = surface points [256 bx, 256 bx + 256) of `row`
-template <bool EVAL>
+// ECAP / ICAP: LDS capacities (entries / items, ICAP >= 4 ECAP); what does not fit is ranked inline, so they trade
+// occupancy (LDS per block) against the speed of blocks whose whole slice sits inside the hand
+template <bool EVAL, int ECAP = GQ_PG_ECAP, int ICAP = GQ_PG_ICAP>
 __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int row, char* lds) {
+  static_assert(ICAP >= 4 * ECAP, "the item area is re-used for 4 floats per entry");
   unsigned long long* s_ekey = reinterpret_cast<unsigned long long*>(lds);
-  unsigned long long* s_pkey = s_ekey + GQ_PG_ECAP;
+  unsigned long long* s_pkey = s_ekey + ECAP;
   GqPgEntry* s_ent = reinterpret_cast<GqPgEntry*>(s_pkey + 256);
-  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_ent + GQ_PG_ECAP);  // entry << 16 | j
+  uint32_t* s_item = reinterpret_cast<uint32_t*>(s_ent + ECAP);  // entry << 16 | j
   float* s_ecl = reinterpret_cast<float*>(s_item);  // after phase B: closest point (link frame) + dis per entry
-  int* s_cnt = reinterpret_cast<int*>(s_item + GQ_PG_ICAP);  // 4 counters + the 64-bit mask of the links in reach
+  int* s_cnt = reinterpret_cast<int*>(s_item + ICAP);  // 4 counters + the 64-bit mask of the links in reach
   float* s_link = reinterpret_cast<float*>(s_cnt + 8);  // L x 24: link transform (12) + padded AABB (8) + occupancy
                                                         // z scale (1) + pad, then L x 4: bounding sphere of the link
                                                         // box in the hand frame (centre, r^2)
@@ -211,9 +214,9 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     if (len == 0u) continue;
     if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
     const int e = atomicAdd(&s_cnt[0], 1);
-    int ib = GQ_PG_ICAP;
-    if (e < GQ_PG_ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
-    if (e < GQ_PG_ECAP && ib + (int)len <= GQ_PG_ICAP) {
+    int ib = ICAP;
+    if (e < ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
+    if (e < ECAP && ib + (int)len <= ICAP) {
       GqPgEntry en;
       en.x = xl.x; en.y = xl.y; en.z = xl.z;
       en.c0 = c0;
@@ -224,9 +227,9 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
       for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
     } else {  // no room: rank the candidates here
       if (g.dbg) atomicAdd(&s_cnt[2], 1);
-      if (e < GQ_PG_ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
+      if (e < ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
       // the part of the item list this entry reserved but does not use must not be read as items
-      for (int i = ib; i < GQ_PG_ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
+      for (int i = ib; i < ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
       const int f0 = g.off[l];
       float bd = GQ_INF_F;
       unsigned bo = 0xffffffffu;
@@ -259,7 +262,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     atomicAdd(&g.dbg[6], (unsigned long long)s_cnt[2]);
     atomicAdd(&g.dbg[7], 1ull);
   }
-  const int n_ent = min(s_cnt[0], GQ_PG_ECAP), n_item = min(s_cnt[1], GQ_PG_ICAP);
+  const int n_ent = min(s_cnt[0], ECAP), n_item = min(s_cnt[1], ICAP);
   // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
   for (int i = tid; i < n_item; i += 256) {
     const uint32_t it = s_item[i];

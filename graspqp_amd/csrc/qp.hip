@@ -266,6 +266,7 @@ static size_t gq_align(size_t v) { return (v + 255) & ~(size_t)255; }
 struct GqQpWs {
   float *resid, *mu, *snap, *runmin;
   int* kstar;
+  unsigned* agg;  // per-block stop-rule aggregates of the fused force-closure step (fcstep_dev.h): 36 words per 4 rows
   size_t total;
 };
 static GqQpWs gq_qp_carve(void* base, int B, int nz, int max_iter) {
@@ -282,6 +283,8 @@ static GqQpWs gq_qp_carve(void* base, int B, int nz, int max_iter) {
   off += gq_align((size_t)B * 4);
   w.kstar = (int*)(c + off);
   off += 256;
+  w.agg = (unsigned*)(c + off);
+  off += gq_align((size_t)((B + 3) / 4) * 36 * 4);
   w.total = off;
   return w;
 }
@@ -339,7 +342,7 @@ static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, flo
 
 // internal (fcstep.hip): table pointers inside a box-QP workspace, and the stand-alone stop-rule launch
 int gq_qp_tables_(void* workspace, size_t workspace_bytes, int B, int nz, int max_iter, float** resid, float** mu,
-                  float** snap, float** runmin, int** kstar) {
+                  float** snap, float** runmin, int** kstar, unsigned** agg) {
   GQ_REQUIRE(workspace && B > 0 && nz > 0 && max_iter >= 1 && max_iter <= 64, "qp_tables: bad arguments");
   GqQpWs w = gq_qp_carve(workspace, B, nz, max_iter);
   GQ_REQUIRE(workspace_bytes >= w.total, "boxqp: workspace too small (%zu < %zu)", workspace_bytes, w.total);
@@ -348,6 +351,7 @@ int gq_qp_tables_(void* workspace, size_t workspace_bytes, int B, int nz, int ma
   *snap = w.snap;
   *runmin = w.runmin;
   *kstar = w.kstar;
+  *agg = w.agg;
   return GQ_OK;
 }
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,

@@ -149,7 +149,10 @@ __device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du
 template <int M, int NC>
 __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int lane, GqLr<M, NC>& S,
                                                  const bool (&live)[NC], const float (&p)[NC], const float (&hu)[NC],
-                                                 const float (&hl)[NC]) {
+                                                 const float (&hl)[NC], float* hist_resid = nullptr,
+                                                 float* hist_mu = nullptr) {
+  // hist_*: lane it keeps the residual / mu of iteration it (max_iter <= 64) for the caller's stop-rule epilogue
+  float h_r = 0.0f, h_m = 0.0f;
   const int nz = g.nz;
   const float m2 = 2.0f * (float)nz;
   float x[NC], su[NC], sl[NC], zu[NC], zl[NC];
@@ -233,6 +236,10 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
       g.resid[(size_t)row * g.max_iter + it] = resid;
       g.mu[(size_t)row * g.max_iter + it] = mu;
     }
+    if (lane == it) {
+      h_r = resid;
+      h_m = mu;
+    }
     if (it == g.max_iter - 1) break;  // qpth returns `best` after the loop; the last update is never used
 
     // reciprocals of s and z once per iteration (v_rcp_f32, 1 ulp): d = z/s, 1/d = s/z, and the corrector's 1/s
@@ -296,6 +303,8 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
       }
     }
   }
+  if (hist_resid) *hist_resid = h_r;
+  if (hist_mu) *hist_mu = h_m;
 }
 
 template <int M, int NC>

@@ -82,10 +82,10 @@ __global__ void gq_sdf_bwd_kernel(const float* __restrict__ g, const float* __re
 
 #include "pen_dev.h"
 
-template <bool EVAL>
+template <bool EVAL, int ECAP, int ICAP>
 __global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
-  gq_pen_grid_body<EVAL>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
+  gq_pen_grid_body<EVAL, ECAP, ICAP>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
 }
 __global__ __launch_bounds__(256) void gq_pen_cells_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
@@ -520,6 +520,7 @@ static void gq_box_of(const float* fv, const int32_t* perm, int64_t a, int64_t b
 }
 
 static unsigned long long* gq_pen_dbg_ = nullptr;
+static int gq_pen_caps_ = 0;  // gq_debug_set_pen_caps: 0 = by launch size, 1 / 2 / 3 = 512 / 256 / 128 entries (A/B runs)
 static int gq_sdf_plain_mapping_ = 0;  // gq_debug_set_sdf_mapping(1): A/B switch for the XCD-aware query placement
 
 // Bound of a 64-face cluster: an oriented box, 16 floats = [centre.xyz, h_u][u.xyz, h_v][v.xyz, h_n][n.xyz, 0].
@@ -635,6 +636,10 @@ int gq_sdf_wave_args_(const gqMeshSet* ms, int64_t n_points, int64_t queries_per
 extern "C" {
 
 // diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
+int gq_debug_set_pen_caps(int mode) {
+  gq_pen_caps_ = mode;
+  return GQ_OK;
+}
 int gq_debug_set_sdf_mapping(int plain) {
   gq_sdf_plain_mapping_ = plain;
   return GQ_OK;
@@ -900,11 +905,22 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   }
   if (penetration_only == 1 && a.occ && a.cand_off) {
     // one pass over the (point, link) pairs, candidate faces from the voxel grid (see gq_pen_grid_kernel)
-    hipExtLaunchKernelGGL(gq_pen_grid_kernel<true>, grid, dim3(256), gq_pen_grid_lds_bytes(a.L), (hipStream_t)stream, e0,
-                          e1, 0, a);
+    // LDS list capacities: smaller lists double the blocks per CU and make THIS kernel faster (168 -> 115 us at 2048
+    // rows) but not the iteration -- the branch it runs beside loses the slots it gains (tools/ab_caps.sh) -- and the
+    // smallest ones overflow into inline ranking; so the large lists stay the default
+    const int caps = gq_pen_caps_ ? gq_pen_caps_ : 1;
+    if (caps == 3)
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 128, 1024>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L, 128, 1024),
+                            (hipStream_t)stream, e0, e1, 0, a);
+    else if (caps == 2)
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 256, 2048>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L, 256, 2048),
+                            (hipStream_t)stream, e0, e1, 0, a);
+    else
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L),
+                            (hipStream_t)stream, e0, e1, 0, a);
   } else if (penetration_only == 9 && a.occ && a.cand_off) {  // diagnostics: the scan without candidate evaluation
-    hipExtLaunchKernelGGL(gq_pen_grid_kernel<false>, grid, dim3(256), gq_pen_grid_lds_bytes(a.L), (hipStream_t)stream,
-                          e0, e1, 0, a);
+    hipExtLaunchKernelGGL((gq_pen_grid_kernel<false, GQ_PG_ECAP, GQ_PG_ICAP>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L),
+                          (hipStream_t)stream, e0, e1, 0, a);
   } else if ((penetration_only == 1 || penetration_only == 3) && workspace != nullptr) {
     // queue-based, load-balanced path without candidate lists (see gq_pen_scan_kernel); 3 forces it for A/B tests
     const size_t cap_link = (size_t)a.B * a.P;

@@ -19,9 +19,6 @@
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream);
 
-#ifndef GQ_HEAD_ROWS
-#define GQ_HEAD_ROWS 4  // fc-head rows (wavefronts) per block of stage A
-#endif
 template <int NC>
 __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
@@ -29,7 +26,12 @@ __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenAr
   if (b < nfc) {  // four rows per block, one wavefront (= one SIMD) each: the fc role occupies B/4 CUs only
     const int wv = (int)threadIdx.x / GQ_WAVE, row = b * GQ_HEAD_ROWS + wv;
     if (wv >= GQ_HEAD_ROWS || row >= f.B) return;
-    gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6);
+    float hr, hm;
+    gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6, &hr, &hm);
+    if (f.agg) {  // large batches: the stop rule as epilogue of the last head block (no stop launch)
+      const int nrow = f.B - b * GQ_HEAD_ROWS < GQ_HEAD_ROWS ? f.B - b * GQ_HEAD_ROWS : GQ_HEAD_ROWS;
+      gq_fc_head_epilogue(f, b, wv, nrow, hr, hm, reinterpret_cast<unsigned*>(gq_lds) + GQ_HEAD_ROWS * f.n * 6);
+    }
   } else if (gx == 0) {  // link-driven query: one block per row (gqPenStepDesc.grid)
     gq_pen_cells_body(p, b - nfc, gq_lds);
   } else {
@@ -117,7 +119,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   }
   const int nfc = (f.B + GQ_HEAD_ROWS - 1) / GQ_HEAD_ROWS;
   const size_t lds_a = std::max(pen->grid ? gq_pen_cells_lds_bytes(p.L, p.P) : gq_pen_grid_lds_bytes(p.L),
-                                (size_t)4 * f.n * 6 * sizeof(float));
+                                (size_t)GQ_HEAD_ROWS * f.n * 6 * sizeof(float) + GQ_HEAD_LDS_WORDS * sizeof(unsigned));
   const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
                                 n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);
   const dim3 grid_a((unsigned)(nfc + (pen->grid ? 1 : gx) * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
@@ -125,7 +127,7 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx, nfc);
   GQ_LAUNCH_CHECK();
   const bool fused_stop = f.B <= 4 * GQ_WAVE && f.max_iter <= 16;
-  if (!fused_stop) {
+  if (!fused_stop && !f.agg) {
     rc = gq_qp_stop_launch_(f.resid, f.mu_tab, f.B, f.max_iter, f.eps, f.not_improved_lim, runmin, f.kstar, f.n_iter, stream);
     if (rc) return rc;
   }

@@ -93,7 +93,7 @@ class GraspStepper:
         self.fk_ws, self.fk_nb = hand.fk_ws(B, self.dev)
         self.fc_nb = ops._size_call("gq_fc_workspace_bytes", ctypes.c_int64(B), n, int(self.fc["n_cone_vecs"]),
                                     int(self.fc["max_iter"]))
-        self.fc_ws = ops._ws(self.fc_nb, self.dev)
+        self.fc_ws = ops._ws(self.fc_nb, self.dev).zero_()  # zero once: block counter of the large-batch stop rule
         self.pen_nb, self.pen_ws = 0, None
         if int(penetration_only) == 3:  # queue path of the penetration query (A/B tests); counters start at zero
             self.pen_nb = ops._size_call("gq_hand_pen_workspace_bytes", ctypes.c_int64(B), ctypes.c_int64(P), self.L)

@@ -97,8 +97,11 @@ int gq_fc_peek(void* workspace, size_t workspace_bytes, int64_t batch, int n_con
 /* Fused form of gq_contact_terms + gq_fc_forward + gq_fc_backward for constant upstream weights (the MALA* loop,
  * scripts/fit.py:434-438: w_dis on E_dis, w_fc on E_fc): two launches per iteration instead of nine, the grasp matrix
  * stays in registers between the cone construction and the QP iterations, and qpth's batch-global stop rule is
- * replayed inside the second kernel.  Inputs as gq_contact_terms; g_contact_pts receives w_dis dE_dis/dp +
- * w_fc dE_fc/dp, g_hand_normals w_dis dE_dis/dnH.  Workspace: gq_fc_workspace_bytes; gq_fc_peek works afterwards. */
+ * replayed inside the second kernel (batches <= 256 rows) or applied by the first kernel's last block to per-block
+ * aggregates (larger batches) -- no launch of its own either way.  Inputs as gq_contact_terms; g_contact_pts receives
+ * w_dis dE_dis/dp + w_fc dE_fc/dp, g_hand_normals w_dis dE_dis/dnH.  Workspace: gq_fc_workspace_bytes; gq_fc_peek
+ * works afterwards.  ZERO-FILL THE WORKSPACE ONCE after allocating it (hipMemset): the block counter of the
+ * large-batch stop rule lives in it and wraps back to zero at the end of every launch.                            */
 int gq_fc_step(const float* dist_sq, const int32_t* sign, const float* obj_dir, const float* closest,
                const float* contact_pts, const float* hand_normals, const float* cog, int64_t batch, int n_contact,
                int n_cone, float friction, float torque_weight, float max_limit, float svd_gain, float values_gain,
@@ -311,6 +314,9 @@ int gq_debug_set_pen_counters(uint64_t* counters /* device, 8 words, or NULL */)
 /* A/B switch: 1 = plain block -> query mapping in gq_sdf_forward_meshset; 0 (default) = XCD-aware (with >= 8 meshes the
  * queries of mesh m run on the blocks b with b % 8 == m % 8, i.e. on one XCD, so each L2 holds only its own meshes). */
 int gq_debug_set_sdf_mapping(int plain);
+/* LDS list capacities of the stand-alone hand-penetration query: 0 = by launch size (default), 1 / 2 / 3 = 512 / 256 /
+ * 128 entries per block (A/B runs; results do not depend on it).                                                  */
+int gq_debug_set_pen_caps(int mode);
 /* grad_dis (B,P) = upstream d E / d dis.  grad_dis == NULL selects the fused E_pen form: the weights are
  * w_pen * [dis > 0] and e_pen (B) = sum_j relu(dis_j) is written as well (core/energy.py:59-61).
  * span / span_acc (optional): the 64 x {min start, max end} shards filled by gq_hand_pen_forward are folded into

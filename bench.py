@@ -316,7 +316,7 @@ def rank_main(args):
     # (3) executed work of the two SDF kernels on the final state (debug counters, stand-alone launches)
     executed = {}
     try:
-        cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
         _C.call("gq_debug_set_pen_counters", _ct.c_void_p(cnt.data_ptr()))
         stream = _C.stream_ptr()
         st._eval_fk(st.hand_pose, st.contact_idx, stream)
@@ -337,6 +337,8 @@ def rank_main(args):
                                    "max_visits_per_query": c[2]},
                     "hand_pen": {"point_link_pairs": B * st.P * hand.L, "pairs_reaching_candidates": c[4],
                                  "point_triangle_tests": c[5], "pairs_ranked_inline": c[6], "blocks": c[7],
+                                 "scanning_wavefronts": c[11], "wavefront_link_sphere_tests": c[8],
+                                 "wavefront_link_sphere_hits": c[9], "point_link_pairs_in_box": c[10],
                                  "link_cell_pairs_walked": c[0] if st.grid is not None else None,
                                  "query": "link-driven (point grid)" if st.grid is not None else "point-driven"}}
     except Exception as e:  # diagnostics must never cost the bench line

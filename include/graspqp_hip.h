@@ -306,11 +306,13 @@ int gq_hand_pen_forward_cells(const gqMeshSet* links, const gqPointGrid* grid, c
                               int64_t n_surface, int64_t batch_each, const float* hand_pose, int pose_dim, const float* Rg,
                               const float* link_T, float* dis, int32_t* link, float* gvec, void* timer /* gqTimer or NULL */,
                               uint64_t* span /* as gq_hand_pen_forward */, void* stream);
-/* diagnostics (NULL = off): 8 device words.  Stand-alone gq_hand_pen_forward (penetration_only = 1) adds [4] (point,
+/* diagnostics (NULL = off): 12 device words.  Stand-alone gq_hand_pen_forward (penetration_only = 1) adds [4] (point,
  * link) pairs that reach candidate evaluation, [5] executed point-triangle rankings, [6] pairs ranked inline because the
- * block's LDS lists were full, [7] blocks; gq_sdf_forward_meshset adds [0] 64-face cluster visits, [1] queries, sets
- * [2] = max visits of a query, adds [3] queries with > 16 visits.  Not read by the fused launches.                  */
-int gq_debug_set_pen_counters(uint64_t* counters /* device, 8 words, or NULL */);
+ * block's LDS lists were full, [7] blocks, [8] (wavefront, link) bounding-sphere tests executed, [9] of those with a point
+ * inside the sphere, [10] (point, link) pairs inside the link box, [11] scanning wavefronts; gq_sdf_forward_meshset adds
+ * [0] 64-face cluster visits, [1] queries, sets [2] = max visits of a query, adds [3] queries with > 16 visits.  Not
+ * read by the fused launches.                                                                                      */
+int gq_debug_set_pen_counters(uint64_t* counters /* device, 12 words, or NULL */);
 /* A/B switch: 1 = plain block -> query mapping in gq_sdf_forward_meshset; 0 (default) = XCD-aware (with >= 8 meshes the
  * queries of mesh m run on the blocks b with b % 8 == m % 8, i.e. on one XCD, so each L2 holds only its own meshes). */
 int gq_debug_set_sdf_mapping(int plain);

@@ -298,7 +298,7 @@ def test_hand_penetration_item_list_overflow(gq):
     om.initialize_from_meshes([fv], surface_points_list=[sp])
     hm.set_parameters(hp.float().cuda(), torch.zeros(be, 4, dtype=torch.long).cuda())
     dis0 = hm.cal_distance(om.surface_points_each, penetration_only=0)
-    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
     gq.C.call("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
     try:
         dis1 = hm.cal_distance(om.surface_points_each, penetration_only=1)
@@ -383,7 +383,7 @@ def test_link_driven_query_equals_point_driven(gq, scene, cells):
         torch.cuda.synchronize()
         return dis, link, gvec
 
-    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
     C("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
     try:
         d_c, l_c, g_c = run("cells")

@@ -50,7 +50,7 @@ for warm in [int(a) for a in sys.argv[1:]] or [20, 200, 1000]:
             pos = ref[0] > 1e-6
             print(f"   {name}: max |dis - grid| on positives {(st.pen_dis[pos] - ref[0][pos]).abs().max().item():.2e}, "
                   f"positives {int(pos.sum())} vs {int((st.pen_dis > 1e-6).sum())}")
-    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
     _C.call("gq_debug_set_pen_counters", ctypes.c_void_p(cnt.data_ptr()))
     fwd(3, False); torch.cuda.synchronize()
     _C.call("gq_debug_set_pen_counters", None)

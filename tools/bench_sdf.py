@@ -26,7 +26,7 @@ for dist in (0.0005, 0.005, 0.02, 0.05, 0.15):
     e0.record()
     for _ in range(100): run()
     e1.record(); torch.cuda.synchronize()
-    cnt = torch.zeros(8, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(12, dtype=torch.int64, device="cuda")
     _C.call("gq_debug_set_pen_counters", _C.ptr(cnt)); run(); torch.cuda.synchronize(); _C.call("gq_debug_set_pen_counters", None)
     print("  visits per query:", float(cnt[0]) / float(cnt[1]), "max", int(cnt[2]), "queries with > 16 visits", int(cnt[3]))
     print(f"offset {dist*1e3:6.1f} mm: {e0.elapsed_time(e1)*10:.1f} us per launch; mean dist {float(d2.sqrt().mean())*1e3:.2f} mm")

@@ -19,7 +19,9 @@
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream);
 
-template <int NC>
+// STOP: the large-batch stop-rule epilogue is compiled in (its 70 extra registers would cost the small-batch
+// instantiation one wavefront per SIMD: 166 instead of 127 VGPRs)
+template <int NC, bool STOP>
 __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenAr
     if (wv >= GQ_HEAD_ROWS || row >= f.B) return;
     float hr, hm;
     gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6, &hr, &hm);
-    if (f.agg) {  // large batches: the stop rule as epilogue of the last head block (no stop launch)
+    if (STOP) {  // large batches: the stop rule as epilogue of the last head block (no stop launch)
       const int nrow = f.B - b * GQ_HEAD_ROWS < GQ_HEAD_ROWS ? f.B - b * GQ_HEAD_ROWS : GQ_HEAD_ROWS;
       gq_fc_head_epilogue(f, b, wv, nrow, hr, hm, reinterpret_cast<unsigned*>(gq_lds) + GQ_HEAD_ROWS * f.n * 6);
     }
@@ -123,8 +125,13 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
   const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
                                 n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);
   const dim3 grid_a((unsigned)(nfc + (pen->grid ? 1 : gx) * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
-  if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2>), grid_a, block, lds_a, st, f, p, gx, nfc);
-  else hipLaunchKernelGGL((gq_stage_a_kernel<1>), grid_a, block, lds_a, st, f, p, gx, nfc);
+  if (f.agg) {
+    if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2, true>), grid_a, block, lds_a, st, f, p, gx, nfc);
+    else hipLaunchKernelGGL((gq_stage_a_kernel<1, true>), grid_a, block, lds_a, st, f, p, gx, nfc);
+  } else {
+    if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2, false>), grid_a, block, lds_a, st, f, p, gx, nfc);
+    else hipLaunchKernelGGL((gq_stage_a_kernel<1, false>), grid_a, block, lds_a, st, f, p, gx, nfc);
+  }
   GQ_LAUNCH_CHECK();
   const bool fused_stop = f.B <= 4 * GQ_WAVE && f.max_iter <= 16;
   if (!fused_stop && !f.agg) {

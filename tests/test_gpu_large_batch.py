@@ -45,6 +45,7 @@ def _rel(a, b, floor=1e-12):
     ("allegro", 12, 4, 8, 256),       # BASELINE configs[3] per rank: 8 meshes x 256 = 2048 rows
     ("shadow_hand", 16, 4, 8, 512),   # configs[2]: 8 meshes x 512 = 4096 rows, nz = 64
     ("robotiq3", 12, 8, 8, 1024),     # configs[4] share: 8 meshes x 1024 = 8192 rows, 8-edge cones, nz = 96
+    ("allegro", 12, 4, 3, 171),       # 513 rows: the last force-closure head block holds ONE row (stop-rule epilogue)
 ])
 def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     from bench import make_initial_state
@@ -62,13 +63,18 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     hp[::97, :3] *= 0.45
     fc_cfg = {"n_cone_vecs": k}
 
-    # (a) captured graph of the fused launches == eager unfused launches, bit for bit, over several iterations
+    # (a) captured graphs (default for this size = per-role launches on two graph branches; then both roles in one grid)
+    # == eager unfused launches, bit for bit, over several iterations
     outs = []
-    for rep in range(2):
+    for rep in range(3):
         s = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg, seed=5)
         s.reset(hp, idx)
         if rep == 1:
             s.capture(iters=2)
+            assert s.graph_mode == "graph branches"
+        if rep == 2:
+            s.capture(fused=True, iters=2)
+            assert s.graph_mode == "one grid"
         for _ in range(4):
             s.step()
         s.flush()
@@ -76,8 +82,9 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
         outs.append((s.energy.clone(), s.hand_pose.clone(), s.contact_idx.clone(), s.grad.clone(), s.terms.clone()))
         assert int(s.n_iter.item()) >= 1
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][3]).all()
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b), "hipGraph replay of the fused launches differs from the eager unfused launches"
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b), "hipGraph replay differs from the eager unfused launches"
     pose, cidx = outs[0][1], outs[0][2]  # accepted state after four iterations: a mix of moved and unmoved rows
 
     # (b) E_fc and its contact-point gradient of the WHOLE batch against the oracle's metric (fp64) run on the same

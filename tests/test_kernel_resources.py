@@ -1,0 +1,42 @@
+"""Register / scratch budgets of the hot kernels, read from the built library's code-object metadata (no GPU needed).
+
+On gfx950 the VGPR count fixes the wavefronts per SIMD (<= 64 -> 8, <= 128 -> 4, <= 168 -> 3).  The kernels below are
+latency-bound and were tuned at a specific occupancy; a change that silently pushes one of them over its boundary costs
+5-15 % (round 2: the stop-rule epilogue took gq_stage_a_kernel from 126 to 166 registers and the penetration role from 4
+to 3 wavefronts per SIMD until it was split off into its own instantiation)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+LIB = os.path.join(ROOT, "graspqp_amd", "lib", "libgraspqp_hip.so")
+
+BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
+    "gq_stage_a_kernel<1, false>": (128, 0),   # config 2: fc head + penetration query, 4 wavefronts per SIMD
+    "gq_sdf_wave_kernel": (128, 16),            # capped by __launch_bounds__(256, 4)
+    "gq_pen_grid_kernel<true, 512, 4096>": (64, 0),
+    "gq_fc_head_kernel<1>": (128, 0),
+    "gq_fk_backward_kernel": (128, 0),
+    "gq_fk_forward_kernel": (170, 160),         # 12 wavefronts per block: 170 is the hardware limit; known spill of
+                                                # 38 words around the contact query (once per query, not in its loops)
+    "gq_stage_b_kernel<1, 4>": (168, 0),
+    "gq_hand_pen_bwd_kernel": (168, 0),
+}
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
+def test_hot_kernels_stay_within_their_register_budget():
+    from kernel_resources import kernel_resources
+
+    res = kernel_resources(LIB)
+    assert len(res) > 40, "metadata of the code objects not found"
+    for name, (vmax, smax) in BUDGET.items():
+        assert name in res, f"{name} is missing from the library (renamed? update the budget table)"
+        r = res[name]
+        assert r["vgpr"] + r["agpr"] <= vmax, (name, r)
+        assert r["scratch"] <= smax, (name, r)
+    spilled = {k: v["scratch"] for k, v in res.items() if v["scratch"] > 0}
+    assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel"}, f"new register spills: {spilled}"

@@ -377,8 +377,9 @@ def rank_main(args):
             pm = _load_json(f"{PROFILE_TAG}_pmc_traffic.json") or _load_json("r01_pmc_traffic.json")
             src = f"profiles/{PROFILE_TAG}_pmc_traffic.json" if _load_json(f"{PROFILE_TAG}_pmc_traffic.json") else "profiles/r01_pmc_traffic.json"
             traffic = None
-            if is_cfg2 and pm and pm.get("gq_pen_grid_kernel<true>"):
-                traffic = pm["gq_pen_grid_kernel<true>"]["hbm_bytes_per_launch"]
+            pen_keys = [k for k in (pm or {}) if k.startswith("gq_pen_grid_kernel<true")]
+            if is_cfg2 and pen_keys:
+                traffic = pm[pen_keys[0]]["hbm_bytes_per_launch"]
             t_iso = (k_ms_events or span_iso_ms or k_ms) * 1e-3
             util = {"note": "physical / executed-work utilisation of the same kernel launched alone (what bounds it is L2 "
                             "round-trip latency: ~6 dependent gathers per block, 3-4 blocks per CU)",
@@ -392,8 +393,13 @@ def rank_main(args):
                 util.update(executed_point_triangle_tests=hp_ex["point_triangle_tests"],
                             executed_tflops=fl / t_iso / 1e12, fp32_alu_frac=fl / t_iso / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                             bruteforce_point_triangle_tests=B * st.P * nf)
-            roof = {"bound": "hbm", "limiter": "latency (L2 round trips); not HBM- or ALU-bound, see utilisation",
-                    "kernel": "gq_pen_grid_kernel (hand-penetration query; in the graph it runs as the pen role of gq_stage_a_kernel)",
+            small = getattr(st, "graph_mode", "one grid") == "one grid"
+            roof = {"bound": "hbm",
+                    "limiter": "latency (L2 round trips); not HBM- or ALU-bound, see utilisation" if small else
+                               "VALU issue slots and registers shared with the concurrent force-closure branch (DESIGN.md section 8); "
+                               "not HBM-bound",
+                    "kernel": "gq_pen_grid_kernel (hand-penetration query; " + ("in the graph it runs as the pen role of gq_stage_a_kernel)"
+                                                                               if small else "its own launch on the second graph branch)"),
                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                     "frac_kind": "algorithmic bytes / kernel time / peak (SURVEY 8d accounting of a TorchSDF-shaped op) -- not a utilisation",
                     "traffic": traffic, "traffic_source": src if traffic else None, "algorithmic_bytes": alg,

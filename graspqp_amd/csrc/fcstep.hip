@@ -21,7 +21,7 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_fc_head_kernel(GqFcStepArgs g) {
 }
 // large batches: GQ_HEAD_ROWS rows per block (one wavefront each) + the stop rule as epilogue of the last block
 template <int NC>
-__global__ __launch_bounds__(GQ_HEAD_ROWS* GQ_WAVE) void gq_fc_head_stop_kernel(GqFcStepArgs g) {
+__global__ __launch_bounds__(GQ_HEAD_ROWS* GQ_WAVE, NC == 1 ? 4 : 2) void gq_fc_head_stop_kernel(GqFcStepArgs g) {
   extern __shared__ float gq_sh[];
   const int blk = (int)blockIdx.x, wv = (int)threadIdx.x / GQ_WAVE, row = blk * GQ_HEAD_ROWS + wv;
   if (row >= g.B) return;

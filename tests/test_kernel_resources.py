@@ -19,6 +19,7 @@ BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
     "gq_sdf_wave_kernel": (128, 16),            # capped by __launch_bounds__(256, 4)
     "gq_pen_grid_kernel<true, 512, 4096>": (64, 0),
     "gq_fc_head_kernel<1>": (128, 0),
+    "gq_fc_head_stop_kernel<1>": (128, 32),     # large batches: capped (4 wavefronts per SIMD beside the other branch); 5 words spill
     "gq_fk_backward_kernel": (128, 0),
     "gq_fk_forward_kernel": (170, 160),         # 12 wavefronts per block: 170 is the hardware limit; known spill of
                                                 # 38 words around the contact query (once per query, not in its loops)
@@ -39,4 +40,4 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert r["vgpr"] + r["agpr"] <= vmax, (name, r)
         assert r["scratch"] <= smax, (name, r)
     spilled = {k: v["scratch"] for k, v in res.items() if v["scratch"] > 0}
-    assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel"}, f"new register spills: {spilled}"
+    assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel", "gq_fc_head_stop_kernel<1>"}, f"new register spills: {spilled}"

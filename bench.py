@@ -407,6 +407,17 @@ def rank_main(args):
         # per-launch table: durations from the rocprofv3 kernel trace and HBM bytes from the PMC passes of THIS command
         # (tools/profile_round.sh writes profiles/<tag>_launches.json); live numbers: launch_groups_ms above
         launches = _load_json(f"{PROFILE_TAG}_launches.json") if is_cfg2 else None
+        # executed instructions per wavefront and VALU issue-slot utilisation of every kernel (SQ counters of the same
+        # command, tools/pmc_instr.sh): the "how far from the machine's limit" figure of kernels that are neither HBM- nor
+        # MFMA-bound
+        instr = _load_json(f"{PROFILE_TAG}_cfg2_instr.json") if is_cfg2 else None
+        if launches and instr:
+            for k in launches.get("kernels", []):
+                rec = instr.get("kernels", {}).get(k["name"])
+                if rec:
+                    k.update(valu_instructions_per_wavefront=rec["valu_per_wave"], wavefronts=rec["wavefronts"],
+                             valu_issue_frac=rec["valu_instructions_x4_cycles_over_duration"] if "valu_instructions_x4_cycles_over_duration" in rec
+                             else rec["valu_per_wave"] * rec["wavefronts"] * 4.0 / (k["avg_us"] * 1e-6 * instr["clock_hz"] * instr["simds"]))
         hand_label = {"allegro": "Allegro", "shadow_hand": "Shadow Hand", "robotiq3": "Robotiq-3F"}.get(args.hand, args.hand)
         metric_name = f"grasp energy+grad evals/sec ({hand_label}, n_contact={args.n_contact})"
         res = {

@@ -69,13 +69,20 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
   int64_t my_idx = 0;
   const bool z_here = !sCP || (int)blockDim.x < 2 * GQ_WAVE;  // otherwise wavefront 1 computes the z-score while it waits
   if (g.has_propose) {  // the proposal of this row, then its forward kinematics: pose and indices are handed over in
-    float g2v[2] = {0.0f, 0.0f};
+    // LDS / registers, no wait for its own stores.  All operands of the proposal are requested BEFORE the barrier behind
+    // which the column means become available (one memory round trip less on the row's critical path).
+    const GqProposePre pp = gq_propose_prefetch(g.pr, row, lane, slot_now);
+    float g2v[2];
     if (sPart) {  // block barrier A: the query wavefronts have left their partial column sums
       __syncthreads();
-      if (lane < g.pr.D) g2v[0] = gq_colsq_finish(sPart, g.pr.B, g.pr.D, lane);
+      g2v[0] = lane < g.pr.D ? gq_colsq_finish(sPart, g.pr.B, g.pr.D, lane) : 0.0f;
+      g2v[1] = 0.0f;  // g2_inline requires D <= 64
       if (row == 0 && lane < g.pr.D) const_cast<float*>(g.pr.g2)[lane] = g2v[0];  // kept observable (g2_scratch)
+    } else {
+      g2v[0] = lane < g.pr.D ? g.pr.g2[lane] : 0.0f;
+      g2v[1] = lane + GQ_WAVE < g.pr.D ? g.pr.g2[lane + GQ_WAVE] : 0.0f;
     }
-    gq_propose_body(g.pr, row, lane, sPose, &my_idx, z_here, slot_now, sPart ? g2v : nullptr);  // LDS / registers, no wait for its own stores
+    gq_propose_finish(g.pr, pp, row, lane, g2v, sPose, &my_idx, z_here);
     gq_wave_sync();
     hp = sPose;
     if (g.n > GQ_WAVE) __threadfence_block();  // contacts beyond the first 64 re-read their indices from memory

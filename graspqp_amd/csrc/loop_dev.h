@@ -28,27 +28,49 @@ struct GqProposeArgs {
   int g2_inline;  // gq_fk_forward only: the block's query wavefronts reduce the column means themselves (no launch)
 };
 
-// one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
+__device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane);
+// Everything the proposal reads except the column means g2: requested up front (gq_fk_forward issues it before the
+// block barrier behind which g2 becomes available, so the proposal itself starts with all operands in registers).
+struct GqProposePre {
+  int64_t st;
+  float gr[2], em[2], hp[2];
+  float us;          // switch draw of contact `lane`
+  int64_t nix, oix;  // drawn / current index of contact `lane`
+  size_t draw0;
+  int ctr;
+};
+__device__ __forceinline__ GqProposePre gq_propose_prefetch(const GqProposeArgs& g, int row, int lane, int slot_now = -1) {
+  GqProposePre p;
+  // slot_now >= 0: the caller has already read slot_ctr[0] (early, so that the dependent loads below need not wait for it)
+  p.ctr = g.slot_ctr ? (slot_now >= 0 ? slot_now : g.slot_ctr[0]) : 0;
+  p.draw0 = g.slot_ctr ? (size_t)(p.ctr % g.slots) * g.B * g.n : 0;
+  p.st = g.step[row];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int d = lane + GQ_WAVE * c;
+    const size_t o = (size_t)row * g.D + d;
+    p.gr[c] = d < g.D ? g.grad[o] : 0.0f;
+    p.em[c] = d < g.D ? g.ema[o] : 0.0f;
+    p.hp[c] = d < g.D ? g.hand_pose[o] : 0.0f;
+  }
+  p.us = 2.0f;
+  p.nix = p.oix = 0;
+  if (lane < g.n) {
+    const size_t o = (size_t)row * g.n + lane;
+    p.us = g.u_switch[p.draw0 + o];
+    p.nix = g.new_idx[p.draw0 + o];
+    p.oix = g.idx[o];
+  }
+  return p;
+}
 // s_pose (LDS, D floats) / my_idx: optional copies of the proposal for the caller's own use (pose element d in s_pose[d],
 // the index of contact `lane` in *my_idx), so that the FK code of the same wavefront need not wait for its own stores;
 // with_z = false leaves the z-score to a separate gq_zscore_row call (e.g. by another, idle wavefront).
-__device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane);
-__device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane, float* s_pose = nullptr,
-                                                int64_t* my_idx = nullptr, bool with_z = true, int slot_now = -1,
-                                                const float* g2_regs = nullptr) {
-  float g2[2];
-  if (g2_regs) {  // the caller has the column means of this lane's elements in registers already
-    g2[0] = g2_regs[0];
-    g2[1] = g2_regs[1];
-  } else {
-    g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
-    g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
-  }
-  // slot_now >= 0: the caller has already read slot_ctr[0] (early, so that the dependent loads below need not wait for it)
-  const int ctr = g.slot_ctr ? (slot_now >= 0 ? slot_now : g.slot_ctr[0]) : 0;
-  const size_t draw0 = g.slot_ctr ? (size_t)(ctr % g.slots) * g.B * g.n : 0;
-  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[1] = ctr + 1;  // read by the accept of this iteration
-  const int64_t st = g.step[row];
+__device__ __forceinline__ void gq_propose_finish(const GqProposeArgs& g, const GqProposePre& p, int row, int lane,
+                                                  const float (&g2)[2], float* s_pose = nullptr, int64_t* my_idx = nullptr,
+                                                  bool with_z = true) {
+  if (g.slot_ctr && row == 0 && lane == 0) g.slot_ctr[1] = p.ctr + 1;  // read by the accept of this iteration
+  const int64_t st = p.st;
   const float s = g.step_size * powf(g.decay, (float)((int)st / g.stepsize_period));  // 32-bit division: st < 2^31
   float v[2] = {0.0f, 0.0f};
   bool bad = false;
@@ -57,15 +79,15 @@ __device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row,
     const int d = lane + GQ_WAVE * c;
     if (d < g.D) {
       const size_t o = (size_t)row * g.D + d;
-      float gr = g.grad[o];
+      float gr = p.gr[c];
       if (g.clip) {
         // torch.clip keeps NaN (then zeroed, optimizer.py:211-213); fminf / fmaxf would turn it into a bound instead
         gr = (gr != gr) ? 0.0f : fminf(fmaxf(gr, -100.0f), 100.0f);
       }
-      float em = g.mu * g2[c] + (1.0f - g.mu) * g.ema[o];
+      float em = g.mu * g2[c] + (1.0f - g.mu) * p.em[c];
       if (em != em) em = 0.0f;
       g.ema[o] = em;
-      v[c] = g.hand_pose[o] - s * gr / (sqrtf(em) + 1e-6f);
+      v[c] = p.hp[c] - s * gr / (sqrtf(em) + 1e-6f);
       bad |= (v[c] != v[c]);
     }
   }
@@ -79,17 +101,29 @@ __device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row,
       if (s_pose) s_pose[d] = pv;
     }
   }
-  for (int c = lane; c < g.n; c += GQ_WAVE) {
+  if (lane < g.n) {
+    const int64_t ix = (p.us < g.switch_p) ? p.nix : p.oix;
+    g.idx_out[(size_t)row * g.n + lane] = ix;
+    if (my_idx) *my_idx = ix;
+  }
+  for (int c = lane + GQ_WAVE; c < g.n; c += GQ_WAVE) {
     const size_t o = (size_t)row * g.n + c;
-    const int64_t ix = (g.u_switch[draw0 + o] < g.switch_p) ? g.new_idx[draw0 + o] : g.idx[o];
-    g.idx_out[o] = ix;
-    if (my_idx && c == lane) *my_idx = ix;
+    g.idx_out[o] = (g.u_switch[p.draw0 + o] < g.switch_p) ? g.new_idx[p.draw0 + o] : g.idx[o];
   }
   if (lane == 0) {
     g.step[row] = st + 1;
     if (g.s_out) g.s_out[row] = s;
   }
   if (with_z) gq_zscore_row(g, row, lane);
+}
+// one wavefront per row: lane d owns pose elements d and d + 64 (D <= 128), lane c owns contact c
+__device__ __forceinline__ void gq_propose_body(const GqProposeArgs& g, int row, int lane, float* s_pose = nullptr,
+                                                int64_t* my_idx = nullptr, bool with_z = true, int slot_now = -1) {
+  float g2[2];
+  g2[0] = lane < g.D ? g.g2[lane] : 0.0f;
+  g2[1] = lane + GQ_WAVE < g.D ? g.g2[lane + GQ_WAVE] : 0.0f;
+  const GqProposePre p = gq_propose_prefetch(g, row, lane, slot_now);
+  gq_propose_finish(g, p, row, lane, g2, s_pose, my_idx, with_z);
 }
 // z = (E - mean_obj) / std_obj (unbiased) over the rows of this row's object (fit.py:403-406)
 __device__ __forceinline__ void gq_zscore_row(const GqProposeArgs& g, int row, int lane) {

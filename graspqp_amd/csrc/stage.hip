@@ -22,7 +22,7 @@ int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter,
 // STOP: the large-batch stop-rule epilogue is compiled in (its 70 extra registers would cost the small-batch
 // instantiation one wavefront per SIMD: 166 instead of 127 VGPRs)
 template <int NC, bool STOP>
-__global__ __launch_bounds__(256) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
+__global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
   if (b < nfc) {  // four rows per block, one wavefront (= one SIMD) each: the fc role occupies B/4 CUs only

@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-from types import SimpleNamespace
 
 import torch
 

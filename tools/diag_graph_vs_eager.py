@@ -2,7 +2,7 @@
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import torch
 from bench import make_initial_state
 from graspqp_amd import ops
 from graspqp_amd.hands import get_hand_spec

@@ -13,7 +13,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from bench import make_initial_state
 from graspqp_amd import ops
 from graspqp_amd.core.object_model import ObjectModel
 from graspqp_amd.hands import get_hand_spec

@@ -187,7 +187,9 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   // Two code paths so that the prefetched boxes are not live across the kinematics: wavefront 0 does the kinematics,
   // the others fetch mesh offsets and cluster boxes of their first query meanwhile; everybody meets at ONE barrier.
   if (wv == 0) {
+    __builtin_amdgcn_s_setprio(3);  // the kinematics wavefront is the block's critical path until the queries start
     gq_fk_forward_row(g, row, lane, sW, sT, sC, sKey, sRad, sCP, sPose, g2_here ? sPart : nullptr);
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     for (int c = 0; c < g.n; c += nw) {
       const GqSdfPre pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + c, lane);

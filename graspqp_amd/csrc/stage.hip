@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcSt
   if (b < nfc) {  // four rows per block, one wavefront (= one SIMD) each: the fc role occupies B/4 CUs only
     const int wv = (int)threadIdx.x / GQ_WAVE, row = b * GQ_HEAD_ROWS + wv;
     if (wv >= GQ_HEAD_ROWS || row >= f.B) return;
+    // the fc rows are the critical path of this launch (one long dependent instruction stream per wavefront); the query
+    // wavefronts that share their SIMDs mostly wait for memory -- let the arbiter prefer the fc wavefront when both are ready
+    __builtin_amdgcn_s_setprio(3);
     float hr, hm;
     gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6, &hr, &hm);
     if (STOP) {  // large batches: the stop rule as epilogue of the last head block (no stop launch)
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBw
   }
   if (b < f.B) {  // one row per block here: 2B blocks = two per CU at B = 256, every tail wavefront has a CU's L1 to itself
     if (threadIdx.x >= GQ_WAVE) return;
+    __builtin_amdgcn_s_setprio(3);  // the longest role of this launch: one dependent instruction stream per row
     gq_fc_tail_body<NC, RPL>(f, b, reinterpret_cast<float*>(gq_lds));
   } else {
     gq_pen_bwd_body(p, b - f.B, gq_lds);

@@ -505,10 +505,10 @@ class GraspStepper:
             self._graph_pending = 0
 
     def capture(self, fork=None, fused=None, iters=1):
-        """Capture one iteration into a hipGraph: FK forward (with the proposal as its head and the self-penetration
-        term), object SDF of the contacts, the two stage launches that hold the force-closure and the penetration
-        branch side by side (``fused``), FK backward (with the energies and the accept step as its tail) -- five
-        launches, no host involvement.  ``fork`` = every role its own launch, the two branches as parallel graph
+        """Capture one iteration into a hipGraph: FK forward (column means of the squared gradient, the proposal, the
+        kinematics and the object SDF of the contacts in one launch), the two stage launches that hold the force-closure
+        and the penetration branch side by side (``fused``), FK backward (with the energies and the accept step as its
+        tail) -- four launches, no host involvement.  ``fork`` = every role its own launch, the two branches as parallel graph
         branches: per-role occupancy instead of one register budget for both roles.  Left at None the mode follows the
         batch: one grid below 512 rows (latency: 3.03 vs 2.53 M evals/s at 256 rows), graph branches from 512 rows on
         (throughput: 3.9 vs 3.6 M at 512, 7.2 vs 6.1 M at 2048, 7.9 vs 6.6 M at 4096; tools/ab_fork.sh).  ``iters``

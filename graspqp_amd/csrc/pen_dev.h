@@ -600,8 +600,13 @@ struct GqPenBwdArgs {
 __host__ __device__ inline size_t gq_pen_bwd_lds_bytes() {
   return (size_t)GQ_PENB_LIST * 6 * 4 + GQ_PENB_K * 4 * 4 + GQ_PENB_LIST;
 }
-// block = 256 threads = one row
+// block = 256 threads = one row.  K = 256-point slices taken up per round (K <= GQ_PENB_K): every slice costs eight
+// registers per thread whether it exists or not, so the launcher picks the smallest K that covers the surface points in
+// one round (K = 10 for the 2500 points of the reference: 120 instead of 162 VGPRs for the stand-alone kernel).  The
+// order of all sums is independent of K.
+template <int K = GQ_PENB_K>
 __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, char* lds) {
+  static_assert(K >= 4 && K <= GQ_PENB_K, "a round must fit the LDS list and the counter table");
   float* s_rec = reinterpret_cast<float*>(lds);
   int* s_cnt = reinterpret_cast<int*>(s_rec + GQ_PENB_LIST * 6);
   unsigned char* s_lnk = reinterpret_cast<unsigned char*>(s_cnt + GQ_PENB_K * 4);
@@ -627,9 +632,9 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
   }
   float e_acc = 0.0f;
   for (int base = 0; base < g.P;) {
-    float w[GQ_PENB_K], dpos[GQ_PENB_K];
+    float w[K], dpos[K];
 #pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
+    for (int k = 0; k < K; ++k) {
       const int pt = base + k * 256 + tid;
       dpos[k] = 0.0f;
       if (g.w) {
@@ -640,21 +645,21 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
         dpos[k] = d > 0.0f ? d : 0.0f;
       }
     }
-    unsigned long long m[GQ_PENB_K];
+    unsigned long long m[K];
 #pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
+    for (int k = 0; k < K; ++k) {
       m[k] = __ballot(w[k] != 0.0f);
       if (lane == 0) s_cnt[k * 4 + wv] = __popcll(m[k]);
     }
     __syncthreads();
     // as many 256-point slices as fit into the LDS list (a slice holds <= 256 entries, so at least four always do);
     // the remaining slices are taken up again by the next round.  The (slice, wave) counts are read once, 16 B each.
-    int4 cnt4[GQ_PENB_K];
+    int4 cnt4[K];
 #pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) cnt4[k] = *reinterpret_cast<const int4*>(s_cnt + k * 4);
+    for (int k = 0; k < K; ++k) cnt4[k] = *reinterpret_cast<const int4*>(s_cnt + k * 4);
     int kfit = 0, run = 0;
 #pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
+    for (int k = 0; k < K; ++k) {
       const int tot = cnt4[k].x + cnt4[k].y + cnt4[k].z + cnt4[k].w;
       if (kfit == k && run + tot <= GQ_PENB_LIST) {
         kfit = k + 1;
@@ -663,7 +668,7 @@ __device__ __forceinline__ void gq_pen_bwd_body(const GqPenBwdArgs& g, int row, 
     }
     run = 0;  // entries before slice k
 #pragma unroll
-    for (int k = 0; k < GQ_PENB_K; ++k) {
+    for (int k = 0; k < K; ++k) {
       if (k < kfit) {
         const int off = run + (wv > 0 ? cnt4[k].x : 0) + (wv > 1 ? cnt4[k].y : 0) + (wv > 2 ? cnt4[k].z : 0);
         run += cnt4[k].x + cnt4[k].y + cnt4[k].z + cnt4[k].w;

@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void gq_pen_cells_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
   gq_pen_cells_body(g, (int)blockIdx.x, gq_lds);
 }
+template <int K>
 __global__ __launch_bounds__(256) void gq_hand_pen_bwd_kernel(GqPenBwdArgs g) {
   extern __shared__ char gq_lds[];
-  gq_pen_bwd_body(g, (int)blockIdx.x, gq_lds);
+  gq_pen_bwd_body<K>(g, (int)blockIdx.x, gq_lds);
 }
 
 // MODE 0 ("exact"): dis is the exact max over links for every point.  A link is skipped for a whole wavefront
@@ -1101,8 +1102,10 @@ int gq_hand_pen_backward(int n_links, const float* surface_points, int64_t n_obj
   int rc0 = gq_pen_bwd_fill(n_links, surface_points, n_obj, n_surface, batch_each, hand_pose, pose_dim, Rg, grad_dis, link,
                             gvec, link_wrench, gRt, dis, w_pen, e_pen, span, span_acc, &a);
   if (rc0) return rc0;
-  hipLaunchKernelGGL(gq_hand_pen_bwd_kernel, dim3((unsigned)a.B), dim3(256), gq_pen_bwd_lds_bytes(), (hipStream_t)stream,
-                     a);
+  if (a.P <= 10 * 256)
+    hipLaunchKernelGGL(gq_hand_pen_bwd_kernel<10>, dim3((unsigned)a.B), dim3(256), gq_pen_bwd_lds_bytes(), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(gq_hand_pen_bwd_kernel<GQ_PENB_K>, dim3((unsigned)a.B), dim3(256), gq_pen_bwd_lds_bytes(), (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

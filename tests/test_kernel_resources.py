@@ -25,7 +25,7 @@ BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
     "gq_fk_forward_kernel": (170, 160),         # 12 wavefronts per block: 170 is the hardware limit; known spill of
                                                 # 38 words around the contact query (once per query, not in its loops)
     "gq_stage_b_kernel<1, 4>": (168, 0),
-    "gq_hand_pen_bwd_kernel": (168, 0),
+    "gq_hand_pen_bwd_kernel<10>": (128, 0),     # <= 2560 surface points: ten slices per round, 4 wavefronts per SIMD
 }
 
 

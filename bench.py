@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL, default) | gloo: rehearsal of the multi-process path "
                     "on fewer GPUs than ranks (ranks share devices round-robin; collectives go through host memory)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--sdf_topk", type=int, default=0, help="clusters per round of the stand-alone contact-SDF kernel: 0 = "
+                    "default (4), 2 / 4 forced (A/B runs)")
     ap.add_argument("--pen_caps", type=int, default=0, help="LDS list capacities of the stand-alone penetration query: 0 = by "
                     "launch size, 1 / 2 / 3 = 512 / 256 / 128 entries per block (A/B runs)")
     ap.add_argument("--cpu_rows", type=int, default=8)
@@ -225,6 +227,8 @@ def rank_main(args):
 
     if args.sdf_plain_mapping:
         _C.call("gq_debug_set_sdf_mapping", 1)
+    if args.sdf_topk:
+        _C.call("gq_debug_set_sdf_topk", int(args.sdf_topk))
     if args.pen_caps:
         _C.call("gq_debug_set_pen_caps", int(args.pen_caps))
     spec = get_hand_spec(args.hand)

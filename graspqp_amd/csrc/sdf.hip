@@ -23,7 +23,8 @@ __global__ void gq_face_prep_kernel(const float* __restrict__ fv, const int32_t*
 
 #include "sdf_dev.h"
 
-__global__ __launch_bounds__(256, 4) void gq_sdf_wave_kernel(GqWaveArgs g) {  // <= 128 VGPRs: 4 wavefronts per SIMD
+template <int TOPK>  // 4: <= 128 VGPRs, 4 wavefronts per SIMD; 2 (large launches): see gq_sdf_wave_query
+__global__ __launch_bounds__(256, TOPK == 4 ? 4 : 5) void gq_sdf_wave_kernel(GqWaveArgs g) {
   int64_t q = (int64_t)blockIdx.x * (blockDim.x / GQ_WAVE) + (threadIdx.x / GQ_WAVE);
   if (g.xcd_meshes) {  // block -> (XCD slot, mesh of that slot, block inside the mesh); see GqWaveArgs
     const int b = (int)blockIdx.x, x = b & 7, i = b >> 3;
@@ -35,7 +36,16 @@ __global__ __launch_bounds__(256, 4) void gq_sdf_wave_kernel(GqWaveArgs g) {  //
   if (q >= g.N) return;
   const int lane = gq_lane();
   const GqSdfPre pre = gq_sdf_wave_prefetch(g, q, lane);
-  gq_sdf_wave_query(g, q, gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]), lane, pre);
+  gq_sdf_wave_query<TOPK>(g, q, gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]), lane, pre);
+}
+static int gq_sdf_topk_ = 0;  // gq_debug_set_sdf_topk: 0 = default (4), 2 / 4 forced (A/B runs)
+static void gq_sdf_wave_launch(const GqWaveArgs& w, unsigned blocks, int64_t n_queries, hipStream_t st) {
+  // two clusters per round: 86 instead of 128 VGPRs and 6 % fewer cluster visits, but every query lives longer --
+  // -1.4 % at 2048 / 4096 rows, +1 % at 512 (tools: bench.py --sdf_topk): four stays the default at every size
+  const int topk = gq_sdf_topk_ ? gq_sdf_topk_ : 4;
+  (void)n_queries;
+  if (topk == 2) hipLaunchKernelGGL(gq_sdf_wave_kernel<2>, dim3(blocks), dim3(256), 0, st, w);
+  else hipLaunchKernelGGL(gq_sdf_wave_kernel<4>, dim3(blocks), dim3(256), 0, st, w);
 }
 
 // ---- point per lane -----------------------------------------------------------------------------------------------
@@ -637,6 +647,10 @@ int gq_sdf_wave_args_(const gqMeshSet* ms, int64_t n_points, int64_t queries_per
 extern "C" {
 
 // diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
+int gq_debug_set_sdf_topk(int topk) {
+  gq_sdf_topk_ = (topk == 2 || topk == 4) ? topk : 0;
+  return GQ_OK;
+}
 int gq_debug_set_pen_caps(int mode) {
   gq_pen_caps_ = mode;
   return GQ_OK;
@@ -849,7 +863,7 @@ int gq_sdf_forward(const float* points, int64_t n_points, const float* face_vert
     w.sign = sign;
     w.normal = normal;
     w.closest = closest;
-    hipLaunchKernelGGL(gq_sdf_wave_kernel, dim3((unsigned)((n_points + 3) / 4)), dim3(256), 0, st, w);
+    gq_sdf_wave_launch(w, (unsigned)((n_points + 3) / 4), n_points, st);
   }
   GQ_LAUNCH_CHECK();
   return GQ_OK;
@@ -872,7 +886,7 @@ int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_p
     w.blocks_per_mesh = (int)((queries_per_mesh + 3) / 4);
     blocks = (unsigned)(8 * w.xcd_meshes * w.blocks_per_mesh);
   }
-  hipLaunchKernelGGL(gq_sdf_wave_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w);
+  gq_sdf_wave_launch(w, blocks, n_points, (hipStream_t)stream);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

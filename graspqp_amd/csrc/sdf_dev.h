@@ -90,7 +90,12 @@ __device__ __forceinline__ float gq_cluster_lb4(const float4 (&r)[4], gq3 p) {
   return fmaf(eu, eu, fmaf(ev, ev, en * en));
 }
 
-// one wavefront answers query q at point p (all lanes pass the same q, p)
+// one wavefront answers query q at point p (all lanes pass the same q, p).  GQ_TOPK = clusters taken up per round: four
+// record loads in flight make a round one L2 round trip for four clusters (latency: the FK forward block, small
+// launches); two keep 40 registers less alive and tighten the bound after every second cluster (throughput: large
+// launches, where registers x lifetime is what the kernels next to it compete for).  The answer does not depend on it:
+// the search is exact and ties go to the smallest original face index.
+template <int GQ_TOPK = 4>
 __device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q, gq3 p, int lane, const GqSdfPre& pre) {
   const int f0 = pre.f0, f1 = pre.f1;
   float best = GQ_INF_F;
@@ -107,7 +112,6 @@ __device__ __forceinline__ void gq_sdf_wave_query(const GqWaveArgs& g, int64_t q
     // soon as the smallest remaining bound exceeds the best distance: for a point at distance d only clusters whose
     // box intersects the ball of radius d are ever touched.
     constexpr int KC = 4;  // 256 clusters (16384 faces) per pass
-    constexpr int GQ_TOPK = 4;
     float ub = GQ_INF_F;
     int visits = 0;
     float lb[KC];

@@ -316,6 +316,9 @@ int gq_debug_set_pen_counters(uint64_t* counters /* device, 12 words, or NULL */
 /* A/B switch: 1 = plain block -> query mapping in gq_sdf_forward_meshset; 0 (default) = XCD-aware (with >= 8 meshes the
  * queries of mesh m run on the blocks b with b % 8 == m % 8, i.e. on one XCD, so each L2 holds only its own meshes). */
 int gq_debug_set_sdf_mapping(int plain);
+/* clusters taken up per round by the stand-alone mesh-distance kernel: 0 = default (4), 2 / 4 forced (A/B runs; results
+ * do not depend on it).                                                                                             */
+int gq_debug_set_sdf_topk(int topk);
 /* LDS list capacities of the stand-alone hand-penetration query: 0 = by launch size (default), 1 / 2 / 3 = 512 / 256 /
  * 128 entries per block (A/B runs; results do not depend on it).                                                  */
 int gq_debug_set_pen_caps(int mode);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(GQ_HEAD_ROWS* GQ_WAVE, NC == 1 ? 4 : 2) void gq_fc_
   gq_fc_head_epilogue(g, blk, wv, nrow, hr, hm, reinterpret_cast<unsigned*>(gq_sh + GQ_HEAD_ROWS * g.n * 6));
 }
 template <int NC, int RPL>
-__global__ __launch_bounds__(GQ_WAVE) void gq_fc_tail_kernel(GqFcStepArgs g) {
+__global__ __launch_bounds__(GQ_WAVE, (NC == 1 && RPL == 0) ? 4 : 1) void gq_fc_tail_kernel(GqFcStepArgs g) {  // NC = 1: 4 wavefronts per SIMD (<= 128 VGPRs)
   extern __shared__ float gq_sh[];
   gq_fc_tail_body<NC, RPL>(g, (int)blockIdx.x, gq_sh);
 }

@@ -168,6 +168,18 @@ __device__ __forceinline__ gq3 gq_fk_contact_point(const GqFkArgs& g, const floa
 
 // block = one row.  has_sdf: blockDim = 64 * (number of query wavefronts); after the kinematics every wavefront answers
 // contact queries c = wave, wave + nw, ... of the row against the row's object mesh (gq_sdf_wave_query).
+// The kinematics alone (no contact queries in the launch: batches > 512 rows, the autograd route): one wavefront per
+// block and no 170-register ceiling, so nothing spills and the query code is not part of the kernel at all.
+__global__ __launch_bounds__(GQ_WAVE) void gq_fk_forward_row_kernel(GqFkArgs g) {
+  __shared__ float sW[64 * 12];
+  __shared__ float sT[64 * 12];
+  __shared__ float sC[256 * 3];
+  __shared__ unsigned long long sKey[64];
+  __shared__ float sRad[256];
+  __shared__ float sPose[128];
+  gq_fk_forward_row(g, (int)blockIdx.x, gq_lane(), sW, sT, sC, sKey, sRad, nullptr, sPose);
+}
+
 __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
   __shared__ float sW[64 * 12];
   __shared__ float sT[64 * 12];
@@ -767,7 +779,10 @@ int gq_fk_forward(const gqHand* h, const float* hand_pose, const int64_t* contac
       if (rc) return rc;
     }
   }
-  hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE * nw), 0, (hipStream_t)stream, a);
+  if (!a.has_sdf)
+    hipLaunchKernelGGL(gq_fk_forward_row_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(gq_fk_forward_kernel, dim3((unsigned)batch), dim3(GQ_WAVE * nw), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL, default) | gloo: rehearsal of the multi-process path "
                     "on fewer GPUs than ranks (ranks share devices round-robin; collectives go through host memory)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--split_self_pen", type=int, default=1, help="0: self penetration stays in the FK forward launch at large "
+                    "batches (A/B runs)")
     ap.add_argument("--sdf_topk", type=int, default=0, help="clusters per round of the stand-alone contact-SDF kernel: 0 = "
                     "default (4), 2 / 4 forced (A/B runs)")
     ap.add_argument("--pen_caps", type=int, default=0, help="LDS list capacities of the stand-alone penetration query: 0 = by "
@@ -239,7 +241,8 @@ def rank_main(args):
     B = len(my_objs) * args.batch_size
     hand = ops.HandHandle(spec)
     st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact,
-                      fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank, point_grid=args.point_grid)
+                      fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank, point_grid=args.point_grid,
+                      split_self_pen=bool(args.split_self_pen))
     hps, idxs = zip(*[make_initial_state(spec, f, args.batch_size, args.n_contact, 1000 + o) for f, o in zip(fvs, my_objs)])
     st.reset(torch.cat(hps).cuda(), torch.cat(idxs).cuda())
 

@@ -54,21 +54,32 @@ struct GqSpenRole {  // third role of stage B: sphere centres + self penetration
   int D;
 };
 
+// block = 4 rows, one wavefront each; LDS per wavefront: 512 B of keys + S x 16 B
+__device__ __forceinline__ void gq_spen_role_body(const GqSpenRole& sp, int blk, int B, char* lds) {
+  const int wv = (int)threadIdx.x / GQ_WAVE, row = blk * 4 + wv;
+  if (row >= B) return;
+  const int S = sp.h.S;
+  char* base = lds + (size_t)wv * ((size_t)S * 16 + 512);
+  unsigned long long* sKey = reinterpret_cast<unsigned long long*>(base);
+  float* sC = reinterpret_cast<float*>(base + 512);
+  float* sRad = sC + 3 * S;
+  const float* hp = sp.hand_pose + (size_t)row * sp.D;
+  gq_spheres_row(sp.h, sp.sa, sp.link_T + (size_t)row * sp.h.L * 12, sp.Rg + (size_t)row * 9, gq_mk(hp[0], hp[1], hp[2]),
+                 row, gq_lane(), sC, sKey, sRad);
+}
+// the same role as a launch of its own (large batches: it rides on the penetration branch of the graph instead of
+// lengthening the FK forward launch that both branches wait for)
+__global__ __launch_bounds__(256) void gq_spheres_kernel(GqSpenRole sp, int B) {
+  extern __shared__ char gq_lds[];
+  gq_spen_role_body(sp, (int)blockIdx.x, B, gq_lds);
+}
+
 template <int NC, int RPL>
 __global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBwdArgs p, GqSpenRole sp) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
   if (b >= 2 * f.B) {
-    const int wv = (int)threadIdx.x / GQ_WAVE, row = (b - 2 * f.B) * 4 + wv;
-    if (row >= f.B) return;
-    const int S = sp.h.S;
-    char* base = gq_lds + (size_t)wv * ((size_t)S * 16 + 512);
-    unsigned long long* sKey = reinterpret_cast<unsigned long long*>(base);
-    float* sC = reinterpret_cast<float*>(base + 512);
-    float* sRad = sC + 3 * S;
-    const float* hp = sp.hand_pose + (size_t)row * sp.D;
-    gq_spheres_row(sp.h, sp.sa, sp.link_T + (size_t)row * sp.h.L * 12, sp.Rg + (size_t)row * 9, gq_mk(hp[0], hp[1], hp[2]),
-                   row, gq_lane(), sC, sKey, sRad);
+    gq_spen_role_body(sp, b - 2 * f.B, f.B, gq_lds);
     return;
   }
   if (b < f.B) {  // one row per block here: 2B blocks = two per CU at B = 256, every tail wavefront has a CU's L1 to itself
@@ -81,6 +92,27 @@ __global__ __launch_bounds__(256) void gq_stage_b_kernel(GqFcStepArgs f, GqPenBw
 }
 
 extern "C" {
+
+int gq_spheres_self_pen(const gqHand* h, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
+                        int64_t batch, float w_spen, float* sphere_centers, float* e_spen, float* g_sphere_centers,
+                        void* stream) {
+  GQ_REQUIRE(h && hand_pose && Rg && link_T && e_spen && g_sphere_centers && batch > 0 && h->S > 0 && h->S <= 256,
+             "spheres_self_pen: bad arguments");
+  GqSpenRole sp{};
+  sp.h = *h;
+  sp.sa.spheres = sphere_centers;
+  sp.sa.e_spen = e_spen;
+  sp.sa.g_spheres = g_sphere_centers;
+  sp.sa.spen_scale = w_spen;
+  sp.Rg = Rg;
+  sp.hand_pose = hand_pose;
+  sp.link_T = link_T;
+  sp.D = pose_dim;
+  hipLaunchKernelGGL(gq_spheres_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), (size_t)4 * ((size_t)h->S * 16 + 512),
+                     (hipStream_t)stream, sp, (int)batch);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
 
 int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream) {
   GQ_REQUIRE(fc && pen, "fc_pen_step: null descriptor");

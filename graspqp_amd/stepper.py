@@ -27,13 +27,14 @@ class GraspStepper:
     def __init__(self, hand: ops.HandHandle, object_meshes: ops.MeshSet, surface_points: torch.Tensor, batch_each: int,
                  n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
                  penetration_only: bool = True, energy_type: str = "graspqp", optimizer: str = "mala_star",
-                 tdg_directions=None, point_grid: int = 0):
+                 tdg_directions=None, point_grid: int = 0, split_self_pen: bool = True):
         """energy_type: "graspqp" (default; the fused launches) | "dexgrasp" | "tdg" (scripts/fit.py:343-347; the
         force-closure term is then one extra launch after the contact terms).  optimizer: "mala_star" | "dexgraspnet"
         (AnnealingDexGraspNet, core/optimizer.py:11-149: no z-score in the temperature, no re-initialisation)."""
         if energy_type not in ("graspqp", "dexgrasp", "tdg") or optimizer not in ("mala_star", "dexgraspnet"):
             raise NotImplementedError(f"energy_type={energy_type!r} / optimizer={optimizer!r}")
         self.energy_type, self.optimizer = energy_type, optimizer
+        self.split_self_pen = bool(split_self_pen)  # False: A/B switch, self penetration stays in the FK forward launch
         self.hand, self.objs = hand, object_meshes
         self.dev = torch.device(device)
         self.surf = surface_points.to(self.dev, torch.float32).contiguous()  # (n_obj,P,3)
@@ -222,6 +223,11 @@ class GraspStepper:
           float(w["E_dis"]), float(w["E_fc"]), f32(self.obj_normal), f32(self.g_cpts), f32(self.g_cnrm), f32(e_fc),
           f32(self.x_sum), i32(self.n_iter), _C.ptr(self.fc_ws), self.fc_nb, st)
 
+    def _eval_spen(self, pose, st):
+        _C.call("gq_spheres_self_pen", self.hand.handle, _C.f32(pose), self.D, _C.f32(self.Rg), _C.f32(self.link_T),
+                ctypes.c_int64(self.B), float(self.w["E_spen"]), _C.f32(self.spheres), _C.f32(self.terms_new[3]),
+                _C.f32(self.g_sph_w), st)
+
     def _eval_pen(self, pose, st, timer=None):
         """Hand-penetration query (the roofline kernel of bench.py) + its backward.  ``timer`` = HIP event pair around
         the query (hipExtLaunchKernelGGL start/stop events).  The query also records its own execution span in
@@ -255,7 +261,12 @@ class GraspStepper:
         # small batches: the contact queries ride along with the kinematics (latency); large ones: their own launch
         # (throughput -- query wavefronts should not hold slots while wavefront 0 of their block does the kinematics)
         attach = fused and self.B <= 512
-        self._eval_fk(pose, idx, st, loop, sdf=attach, spheres=not fused)
+        # per-role launches, 512..1023 rows: sphere centres + self penetration leave the FK forward launch (which both
+        # branches wait for) and ride on the penetration branch, as in the fused form (same device code, same bits):
+        # +3.9 % at 512 rows.  From 2048 rows on that branch is the longer one (-1.1 %), and a third graph branch for the
+        # role loses at every size (-3.6 % at 512, -1 % at 1024, 0 at 2048), so there it stays in the FK forward launch.
+        split_spen = not fused and self.S > 0 and 512 <= self.B < 1024 and self.split_self_pen
+        self._eval_fk(pose, idx, st, loop, sdf=attach, spheres=not fused and not split_spen)
         if fused:
             if not attach:
                 _C.call("gq_sdf_forward_meshset", self.objs.handle, _C.f32(self.cpts), self.B * self.n, self.be * self.n,
@@ -265,12 +276,16 @@ class GraspStepper:
             _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
         elif not fork:
             self._eval_contacts(st)
+            if split_spen:
+                self._eval_spen(pose, st)
             self._eval_pen(pose, st, timer)
         else:
             main = torch.cuda.current_stream()
             sb = self._side
             sb.wait_stream(main)
             self._eval_contacts(st)
+            if split_spen:
+                self._eval_spen(pose, ctypes.c_void_p(sb.cuda_stream))
             self._eval_pen(pose, ctypes.c_void_p(sb.cuda_stream), timer)
             main.wait_stream(sb)
         self._eval_tail(pose, idx, st, loop)

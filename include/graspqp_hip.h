@@ -337,6 +337,14 @@ int gq_self_pen_forward(const gqHand* h, const float* sphere_centers /* (B,S,3) 
                         float grad_scale, float* e_spen /* (B) */,
                         float* g_centers /* (B,S,3) grad_scale * dE/dcentre */, void* stream);
 
+/* The same term straight from the kinematics of gq_fk_forward (world sphere centres from link_T / Rg / the translation in
+ * hand_pose, then the pair scan): the self-penetration role of gq_fc_pen_step as a launch of its own, bit-identical to
+ * it and to the e_spen tail of gq_fk_forward.  For large batches, where it rides on the penetration branch of the
+ * iteration instead of lengthening the FK forward launch.  sphere_centers (B,S,3) may be NULL.                     */
+int gq_spheres_self_pen(const gqHand* h, const float* hand_pose, int pose_dim, const float* Rg, const float* link_T,
+                        int64_t batch, float w_spen, float* sphere_centers, float* e_spen /* (B) */,
+                        float* g_sphere_centers /* (B,S,3) w_spen * dE/dcentre */, void* stream);
+
 /* ---- energy composition: core/energy.py:25-28,47-62 and scripts/fit.py:434-438 ---------------------------- */
 int gq_contact_terms(const float* dist_sq, const int32_t* sign, const float* onrm, const float* closest,
                      const float* contact_pts, const float* contact_normals, int64_t batch, int n_contact, float w_dis,

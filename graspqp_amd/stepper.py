@@ -525,8 +525,8 @@ class GraspStepper:
         and the penetration branch side by side (``fused``), FK backward (with the energies and the accept step as its
         tail) -- four launches, no host involvement.  ``fork`` = every role its own launch, the two branches as parallel graph
         branches: per-role occupancy instead of one register budget for both roles.  Left at None the mode follows the
-        batch: one grid below 512 rows (latency: 3.03 vs 2.53 M evals/s at 256 rows), graph branches from 512 rows on
-        (throughput: 3.9 vs 3.6 M at 512, 7.2 vs 6.1 M at 2048, 7.9 vs 6.6 M at 4096; tools/ab_fork.sh).  ``iters``
+        batch: one grid below 512 rows (latency: 3.14 vs 2.61 M evals/s at 256 rows), graph branches from 512 rows on
+        (throughput: 4.5 vs 4.1 M at 512, 8.0 vs 6.5 M at 2048, 8.7 vs 6.9 M at 4096; tools/ab_fork.sh).  ``iters``
         > 1 captures that many consecutive iterations in one graph (every kernel finds its random draws through the
         device-side slot counter), which removes the graph-launch gap between iterations; ``step`` then replays once
         per ``iters`` calls and ``flush`` runs a remainder.  The state is saved and restored around the warm-up +

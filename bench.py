@@ -48,10 +48,10 @@ def parse_args(argv=None):
     ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
     ap.add_argument("--hand", default="allegro")
     ap.add_argument("--fork", type=int, default=-1, help="1: every role its own launch, the two branches of the evaluation as "
-                    "parallel hipGraph branches; -1 (default): follow the batch size (from 512 rows on)")
+                    "parallel hipGraph branches; -1 (default): follow the batch size (from 384 rows on)")
     ap.add_argument("--graph_iters", type=int, default=8, help="MALA* iterations captured per hipGraph (reduced to a divisor of --steps)")
     ap.add_argument("--fused", type=int, default=-1, help="1: force-closure and penetration branches share two launches; "
-                    "-1 (default): follow the batch size (below 512 rows)")
+                    "-1 (default): follow the batch size (below 384 rows)")
     ap.add_argument("--graph", type=int, default=1, help="replay the iteration from hipGraphs (1, default) or launch eagerly (0)")
     ap.add_argument("--dist_backend", default="nccl", help="nccl (= RCCL, default) | gloo: rehearsal of the multi-process path "
                     "on fewer GPUs than ranks (ranks share devices round-robin; collectives go through host memory)")

@@ -261,11 +261,11 @@ class GraspStepper:
         # small batches: the contact queries ride along with the kinematics (latency); large ones: their own launch
         # (throughput -- query wavefronts should not hold slots while wavefront 0 of their block does the kinematics)
         attach = fused and self.B <= 512
-        # per-role launches, 512..1023 rows: sphere centres + self penetration leave the FK forward launch (which both
+        # per-role launches, 384..1023 rows: sphere centres + self penetration leave the FK forward launch (which both
         # branches wait for) and ride on the penetration branch, as in the fused form (same device code, same bits):
         # +3.9 % at 512 rows.  From 2048 rows on that branch is the longer one (-1.1 %), and a third graph branch for the
         # role loses at every size (-3.6 % at 512, -1 % at 1024, 0 at 2048), so there it stays in the FK forward launch.
-        split_spen = not fused and self.S > 0 and 512 <= self.B < 1024 and self.split_self_pen
+        split_spen = not fused and self.S > 0 and 384 <= self.B < 1024 and self.split_self_pen
         self._eval_fk(pose, idx, st, loop, sdf=attach, spheres=not fused and not split_spen)
         if fused:
             if not attach:
@@ -525,8 +525,9 @@ class GraspStepper:
         and the penetration branch side by side (``fused``), FK backward (with the energies and the accept step as its
         tail) -- four launches, no host involvement.  ``fork`` = every role its own launch, the two branches as parallel graph
         branches: per-role occupancy instead of one register budget for both roles.  Left at None the mode follows the
-        batch: one grid below 512 rows (latency: 3.14 vs 2.61 M evals/s at 256 rows), graph branches from 512 rows on
-        (throughput: 4.5 vs 4.1 M at 512, 8.0 vs 6.5 M at 2048, 8.7 vs 6.9 M at 4096; tools/ab_fork.sh).  ``iters``
+        batch: one grid below 384 rows (latency: 3.14 vs 2.61 M evals/s at 256 rows, 3.07 vs 3.00 at 320), graph branches
+        from 384 rows on (throughput: 3.67 vs 3.52 M at 384, 4.5 vs 4.1 M at 512, 8.0 vs 6.5 M at 2048, 8.7 vs 6.9 M at
+        4096; tools/ab_fork.sh).  ``iters``
         > 1 captures that many consecutive iterations in one graph (every kernel finds its random draws through the
         device-side slot counter), which removes the graph-launch gap between iterations; ``step`` then replays once
         per ``iters`` calls and ``flush`` runs a remainder.  The state is saved and restored around the warm-up +
@@ -536,7 +537,7 @@ class GraspStepper:
         saved = [t.clone() for t in keep]
         rng = (self.gen.get_state(), self._draw_pos)
         if fused is None:
-            fused = self.B < 512 if fork is None else not fork
+            fused = self.B < 384 if fork is None else not fork
         if fork is None:
             fork = not fused
         fused = fused and self._can_fuse

@@ -60,6 +60,8 @@ def parse_args(argv=None):
                     "batches (A/B runs)")
     ap.add_argument("--sdf_topk", type=int, default=0, help="clusters per round of the stand-alone contact-SDF kernel: 0 = "
                     "default (4), 2 / 4 forced (A/B runs)")
+    ap.add_argument("--pen_ppt", type=int, default=0, help="surface points per thread of the penetration query: 0 = default, "
+                    "1 / 2 forced (A/B runs)")
     ap.add_argument("--pen_caps", type=int, default=0, help="LDS list capacities of the stand-alone penetration query: 0 = by "
                     "launch size, 1 / 2 / 3 = 512 / 256 / 128 entries per block (A/B runs)")
     ap.add_argument("--cpu_rows", type=int, default=8)
@@ -231,6 +233,8 @@ def rank_main(args):
         _C.call("gq_debug_set_sdf_mapping", 1)
     if args.sdf_topk:
         _C.call("gq_debug_set_sdf_topk", int(args.sdf_topk))
+    if args.pen_ppt:
+        _C.call("gq_debug_set_pen_ppt", int(args.pen_ppt))
     if args.pen_caps:
         _C.call("gq_debug_set_pen_caps", int(args.pen_caps))
     spec = get_hand_spec(args.hand)

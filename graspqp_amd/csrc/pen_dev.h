@@ -110,35 +110,47 @@ __device__ __forceinline__ unsigned long long gq_rank_key(float d2, unsigned ori
   return ((unsigned long long)b << 32) | ((unsigned long long)(orig_local & 0xffffu) << 16) | (f_local & 0xffffu);
 }
 // LDS of one block (bytes): entries, entry keys, items (re-used for the finished entries), point keys, counters, links
-__host__ __device__ inline size_t gq_pen_grid_lds_bytes(int L, int ecap = GQ_PG_ECAP, int icap = GQ_PG_ICAP) {
-  return (size_t)ecap * (sizeof(GqPgEntry) + 8) + (size_t)icap * 4 + 256 * 8 + 32 + (size_t)L * 28 * 4;
+__host__ __device__ inline size_t gq_pen_grid_lds_bytes(int L, int ecap = GQ_PG_ECAP, int icap = GQ_PG_ICAP, int ppt = 1) {
+  return (size_t)ecap * (sizeof(GqPgEntry) + 8) + (size_t)icap * 4 + (size_t)ppt * 256 * 8 + 32 + (size_t)L * 28 * 4;
 }
-// block = 256 threads = surface points [256 bx, 256 bx + 256) of `row`
+// block = 256 threads = surface points [256 PPT bx, 256 PPT (bx + 1)) of `row`: PPT points per thread (slice h of the
+// block = points 256 (PPT bx + h) + tid).
 // ECAP / ICAP: LDS capacities (entries / items, ICAP >= 4 ECAP); what does not fit is ranked inline, so they trade
-// occupancy (LDS per block) against the speed of blocks whose whole slice sits inside the hand
-template <bool EVAL, int ECAP = GQ_PG_ECAP, int ICAP = GQ_PG_ICAP>
+// occupancy (LDS per block) against the speed of blocks whose whole slice sits inside the hand.
+// PPT = 2 halves the blocks and wavefronts of a launch: the prologue (link table, bounding spheres), the per-link loop
+// overhead and the three list phases are shared by twice the points, at the same LDS lists.  The results do not depend
+// on it (the list phases are order-independent; overflow is ranked inline with the same arithmetic).
+template <bool EVAL, int ECAP = GQ_PG_ECAP, int ICAP = GQ_PG_ICAP, int PPT = 1>
 __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int row, char* lds) {
   static_assert(ICAP >= 4 * ECAP, "the item area is re-used for 4 floats per entry");
+  static_assert(PPT == 1 || PPT == 2, "one or two points per thread");
   unsigned long long* s_ekey = reinterpret_cast<unsigned long long*>(lds);
   unsigned long long* s_pkey = s_ekey + ECAP;
-  GqPgEntry* s_ent = reinterpret_cast<GqPgEntry*>(s_pkey + 256);
+  GqPgEntry* s_ent = reinterpret_cast<GqPgEntry*>(s_pkey + 256 * PPT);
   uint32_t* s_item = reinterpret_cast<uint32_t*>(s_ent + ECAP);  // entry << 16 | j
   float* s_ecl = reinterpret_cast<float*>(s_item);  // after phase B: closest point (link frame) + dis per entry
-  int* s_cnt = reinterpret_cast<int*>(s_item + ICAP);  // 4 counters + the 64-bit mask of the links in reach
+  int* s_cnt = reinterpret_cast<int*>(s_item + ICAP);  // 4 counters + 2 x the 64-bit mask of the links in reach of a slice
   float* s_link = reinterpret_cast<float*>(s_cnt + 8);  // L x 24: link transform (12) + padded AABB (8) + occupancy
                                                         // z scale (1) + pad, then L x 4: bounding sphere of the link
                                                         // box in the hand frame (centre, r^2)
   float* s_sph = s_link + g.L * 24;
   const int tid = threadIdx.x;
-  const int pt = bx * 256 + tid;
-  const unsigned block_id = (unsigned)(bx + row * ((g.P + 255) / 256));
+  const int n_slices = (g.P + 255) / 256;
+  const unsigned block_id = (unsigned)(bx + row * ((n_slices + PPT - 1) / PPT));
   if (g.span && tid == 0) gq_span_open(g.span, block_id);
-  const bool ok = pt < g.P;
   const int obj = row / g.batch_each;
-  const float* sp = g.surf + ((size_t)obj * g.P + (ok ? pt : 0)) * 3;
   const float* hp = g.hand_pose + (size_t)row * g.D;
   const float* R = g.Rg + (size_t)row * 9;
-  const gq3 xh = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+  int pt[PPT];
+  bool ok[PPT];
+  gq3 xh[PPT];
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    pt[h] = (bx * PPT + h) * 256 + tid;
+    ok[h] = pt[h] < g.P;
+    const float* sp = g.surf + ((size_t)obj * g.P + (ok[h] ? pt[h] : 0)) * 3;
+    xh[h] = gq_mtv(R, gq_mk(sp[0] - hp[0], sp[1] - hp[1], sp[2] - hp[2]));
+  }
   for (int i = tid; i < g.L * 24; i += 256) {  // link transforms / boxes: independent loads, one round trip
     const int l = i / 24, k = i % 24;
     float v = 0.0f;
@@ -147,120 +159,151 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     else if (k == 20) v = g.occ_invz[l];
     s_link[i] = v;
   }
-  float4 pslice = make_float4(0, 0, 0, -1.0f);
-  if (g.patch && tid < g.L) pslice = *reinterpret_cast<const float4*>(g.patch + ((size_t)obj * ((g.P + 255) / 256) + bx) * 4);
+  float4 pslice[PPT];
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    pslice[h] = make_float4(0, 0, 0, -1.0f);
+    const int sl = bx * PPT + h;
+    if (g.patch && tid < g.L && sl < n_slices) pslice[h] = *reinterpret_cast<const float4*>(g.patch + ((size_t)obj * n_slices + sl) * 4);
+  }
   const bool has_faces = tid < g.L && g.off[tid + 1] > g.off[tid];
   if (tid < 4) s_cnt[tid] = 0;  // [0] entries, [1] items, [2] inline-ranked entries, [3] rankings (diagnostics)
-  s_pkey[tid] = 0ull;
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) s_pkey[h * 256 + tid] = 0ull;
   __syncthreads();
-  if (tid < g.L) {  // bounding sphere of every link box in the hand frame + which links can reach this block's slice at all
+  if (tid < g.L) {  // bounding sphere of every link box in the hand frame + which links can reach the block's slices at all
     const int l = tid;
     const float* T = s_link + l * 24;
     const float* bb = T + 12;
     const gq3 c = gq_mk(0.5f * (bb[0] + bb[4]), 0.5f * (bb[1] + bb[5]), 0.5f * (bb[2] + bb[6]));
-    const gq3 h = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
+    const gq3 hh = gq_mk(0.5f * (bb[4] - bb[0]), 0.5f * (bb[5] - bb[1]), 0.5f * (bb[6] - bb[2]));
     const gq3 sc = gq_mk(T[0] * c.x + T[1] * c.y + T[2] * c.z + T[3], T[4] * c.x + T[5] * c.y + T[6] * c.z + T[7],
                          T[8] * c.x + T[9] * c.y + T[10] * c.z + T[11]);
-    const float r2 = has_faces ? gq_dot(h, h) * 1.001f + 1e-12f : -1.0f;
+    const float r2 = has_faces ? gq_dot(hh, hh) * 1.001f + 1e-12f : -1.0f;
     s_sph[l * 4 + 0] = sc.x;
     s_sph[l * 4 + 1] = sc.y;
     s_sph[l * 4 + 2] = sc.z;
     s_sph[l * 4 + 3] = r2;
-    bool reach = r2 >= 0.0f;
-    if (g.patch && reach) {
-      // a point of the slice can only be inside the link's (padded) box if the slice's bounding sphere touches the box:
-      // distance of the slice centre to the box, in the link frame (tighter than sphere against sphere for the long,
-      // thin finger links: 7.9 -> fewer links per block survive)
-      const gq3 pc = gq_mtv(R, gq_mk(pslice.x - hp[0], pslice.y - hp[1], pslice.z - hp[2]));  // slice centre, hand frame
-      const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-      const gq3 pl = gq_mtv(Rl, pc - gq_mk(T[3], T[7], T[11]));
-      reach = gq_aabb_dist2(bb, pl) <= pslice.w * pslice.w * 1.0002f + 1e-10f;
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      bool reach = r2 >= 0.0f && (bx * PPT + h) < n_slices;
+      if (g.patch && reach) {
+        // a point of the slice can only be inside the link's (padded) box if the slice's bounding sphere touches the box:
+        // distance of the slice centre to the box, in the link frame (tighter than sphere against sphere for the long,
+        // thin finger links)
+        const gq3 pc = gq_mtv(R, gq_mk(pslice[h].x - hp[0], pslice[h].y - hp[1], pslice[h].z - hp[2]));  // slice centre, hand frame
+        const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+        const gq3 pl = gq_mtv(Rl, pc - gq_mk(T[3], T[7], T[11]));
+        reach = gq_aabb_dist2(bb, pl) <= pslice[h].w * pslice[h].w * 1.0002f + 1e-10f;
+      }
+      const unsigned long long m = __ballot(reach);  // links 0 .. L-1 sit in wavefront 0 (L <= 64)
+      if (tid == 0) *reinterpret_cast<unsigned long long*>(s_cnt + 4 + 2 * h) = m;
     }
-    const unsigned long long m = __ballot(reach);  // links 0 .. L-1 sit in wavefront 0 (L <= 64)
-    if (tid == 0) *reinterpret_cast<unsigned long long*>(s_cnt + 4) = m;
   }
   __syncthreads();
-  const unsigned long long lmask = *reinterpret_cast<const unsigned long long*>(s_cnt + 4);
-  if (lmask == 0ull) {  // no link can touch this slice: nothing penetrates
-    if (ok) g.dis[(size_t)row * g.P + pt] = -1e30f;
+  unsigned long long lmask[PPT], lany = 0ull;
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    lmask[h] = *reinterpret_cast<const unsigned long long*>(s_cnt + 4 + 2 * h);
+    lany |= lmask[h];
+  }
+  if (lany == 0ull) {  // no link can touch these slices: nothing penetrates
+#pragma unroll
+    for (int h = 0; h < PPT; ++h)
+      if (ok[h]) g.dis[(size_t)row * g.P + pt[h]] = -1e30f;
     if (g.dbg && tid == 0) atomicAdd(&g.dbg[7], 1ull);
     if (g.span && tid == 0) gq_span_close(g.span, block_id);
     return;
   }
   // ---- A: scan -------------------------------------------------------------------------------------------------
-  float in_dis = 0.0f;  // result of entries this thread had to rank inline (capacity overflow)
-  int in_link = -1;
-  gq3 in_cl = gq_mk(0, 0, 0), in_xl = gq_mk(0, 0, 0);
+  float in_dis[PPT];  // result of entries this thread had to rank inline (capacity overflow)
+  int in_link[PPT];
+  gq3 in_cl[PPT], in_xl[PPT];
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    in_dis[h] = 0.0f;
+    in_link[h] = -1;
+    in_cl[h] = in_xl[h] = gq_mk(0, 0, 0);
+  }
   if (g.dbg && (tid & 63) == 0) {  // [8] (wavefront, link) sphere tests executed, [11] wavefronts that scan
-    atomicAdd(&g.dbg[8], (unsigned long long)__builtin_popcountll(lmask));
+    atomicAdd(&g.dbg[8], (unsigned long long)__builtin_popcountll(lany));
     atomicAdd(&g.dbg[11], 1ull);
   }
-  for (unsigned long long rest = lmask; rest != 0ull; rest &= rest - 1ull) {  // links in reach of the slice, ascending
+  for (unsigned long long rest = lany; rest != 0ull; rest &= rest - 1ull) {  // links in reach of the slices, ascending
     const int l = __builtin_ctzll(rest);
-    // bounding sphere first (one LDS read, 7 VALU ops); the surface points are Morton-ordered, so a wavefront is a
-    // compact patch of the object and most (wavefront, link) pairs end here
+    // bounding sphere first (one LDS read, 7 VALU ops per point); the surface points are Morton-ordered, so a wavefront is
+    // a compact patch of the object and most (wavefront, link) pairs end here
     const float4 sph = *reinterpret_cast<const float4*>(s_sph + l * 4);
-    const gq3 dc = xh - gq_mk(sph.x, sph.y, sph.z);
-    const bool near = ok && gq_dot(dc, dc) <= sph.w;
-    if (__ballot(near) == 0ull) continue;
+    bool near[PPT], any_near = false;
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      const gq3 dc = xh[h] - gq_mk(sph.x, sph.y, sph.z);
+      near[h] = ok[h] && ((lmask[h] >> l) & 1ull) && gq_dot(dc, dc) <= sph.w;
+      any_near |= near[h];
+    }
+    if (__ballot(any_near) == 0ull) continue;
     if (g.dbg && (tid & 63) == 0) atomicAdd(&g.dbg[9], 1ull);  // (wavefront, link) pairs with a point inside the sphere
     const float* T = s_link + l * 24;
     const float Rl[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    const gq3 xl = gq_mtv(Rl, xh - gq_mk(T[3], T[7], T[11]));
     const float* bb = T + 12;
-    if (!(near && gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
-    if (g.dbg) atomicAdd(&g.dbg[10], 1ull);  // (point, link) pairs inside the link box
-    const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
-    const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
-    if (!EVAL) {
-      if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
-      continue;
-    }
-    // (no look-up of the occupancy bit first: a voxel that is not occupied has an empty candidate list -- one dependent
-    // round trip less)
-    const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
-    const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
-    if (len == 0u) continue;
-    if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
-    const int e = atomicAdd(&s_cnt[0], 1);
-    int ib = ICAP;
-    if (e < ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
-    if (e < ECAP && ib + (int)len <= ICAP) {
-      GqPgEntry en;
-      en.x = xl.x; en.y = xl.y; en.z = xl.z;
-      en.c0 = c0;
-      en.pt = (uint16_t)tid;
-      en.link = (uint16_t)l;
-      s_ent[e] = en;
-      s_ekey[e] = ~0ull;
-      for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
-    } else {  // no room: rank the candidates here
-      if (g.dbg) atomicAdd(&s_cnt[2], 1);
-      if (e < ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
-      // the part of the item list this entry reserved but does not use must not be read as items
-      for (int i = ib; i < ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
-      const int f0 = g.off[l];
-      float bd = GQ_INF_F;
-      unsigned bo = 0xffffffffu;
-      int bi = -1;
-      for (uint32_t c = c0; c < c0 + len; ++c) {
-        const int f = f0 + (int)g.cand_idx[c];
-        const GqFace fc = g.rec[f];
-        const float d2 = gq_tri_rank(fc, xl - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
-        const unsigned orig = (unsigned)__float_as_int(fc.r5.z);
-        if (d2 < bd || (d2 == bd && orig < bo)) {
-          bd = d2;
-          bo = orig;
-          bi = f;
-        }
+#pragma unroll
+    for (int h = 0; h < PPT; ++h) {
+      if (!near[h]) continue;
+      const gq3 xl = gq_mtv(Rl, xh[h] - gq_mk(T[3], T[7], T[11]));
+      if (!(gq_aabb_dist2(bb, xl) <= 0.0f)) continue;
+      if (g.dbg) atomicAdd(&g.dbg[10], 1ull);  // (point, link) pairs inside the link box
+      const float ux = (xl.x - bb[0]) * bb[3], uy = (xl.y - bb[1]) * bb[7], uz = (xl.z - bb[2]) * T[20];
+      const int ix = min(max((int)ux, 0), 31), iy = min(max((int)uy, 0), 31), iz = min(max((int)uz, 0), 31);
+      if (!EVAL) {
+        if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
+        continue;
       }
-      const GqSdfOut o = gq_tri_finish(g.rec[bi], xl);
-      const float dis = sqrtf(o.dist2 + 1e-8f);
-      if (o.sign < 0 && dis > in_dis) {
-        in_dis = dis;
-        in_link = l;
-        in_cl = o.closest;
-        in_xl = xl;
+      // (no look-up of the occupancy bit first: a voxel that is not occupied has an empty candidate list -- one dependent
+      // round trip less)
+      const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
+      const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
+      if (len == 0u) continue;
+      if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
+      const int e = atomicAdd(&s_cnt[0], 1);
+      int ib = ICAP;
+      if (e < ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
+      if (e < ECAP && ib + (int)len <= ICAP) {
+        GqPgEntry en;
+        en.x = xl.x; en.y = xl.y; en.z = xl.z;
+        en.c0 = c0;
+        en.pt = (uint16_t)(h * 256 + tid);
+        en.link = (uint16_t)l;
+        s_ent[e] = en;
+        s_ekey[e] = ~0ull;
+        for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
+      } else {  // no room: rank the candidates here
+        if (g.dbg) atomicAdd(&s_cnt[2], 1);
+        if (e < ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
+        // the part of the item list this entry reserved but does not use must not be read as items
+        for (int i = ib; i < ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
+        const int f0 = g.off[l];
+        float bd = GQ_INF_F;
+        unsigned bo = 0xffffffffu;
+        int bi = -1;
+        for (uint32_t c = c0; c < c0 + len; ++c) {
+          const int f = f0 + (int)g.cand_idx[c];
+          const GqFace fc = g.rec[f];
+          const float d2 = gq_tri_rank(fc, xl - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
+          const unsigned orig = (unsigned)__float_as_int(fc.r5.z);
+          if (d2 < bd || (d2 == bd && orig < bo)) {
+            bd = d2;
+            bo = orig;
+            bi = f;
+          }
+        }
+        const GqSdfOut o = gq_tri_finish(g.rec[bi], xl);
+        const float dis = sqrtf(o.dist2 + 1e-8f);
+        if (o.sign < 0 && dis > in_dis[h]) {
+          in_dis[h] = dis;
+          in_link[h] = l;
+          in_cl[h] = o.closest;
+          in_xl[h] = xl;
+        }
       }
     }
   }
@@ -305,13 +348,15 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
   }
   __syncthreads();
   // ---- D: outputs ---------------------------------------------------------------------------------------------------
-  if (ok) {
+#pragma unroll
+  for (int h = 0; h < PPT; ++h) {
+    if (!ok[h]) continue;
     // dis for every point (coalesced 4 B); link and gradient only where a link is penetrated -- nothing downstream
     // reads them elsewhere (energy.py:59-61 zeroes dis <= 0), the caller provides zero-initialised buffers
-    float best_dis = in_dis;
-    int best_link = in_link;
-    gq3 best_cl = in_cl, best_xl = in_xl;
-    const unsigned long long pk = s_pkey[tid];
+    float best_dis = in_dis[h];
+    int best_link = in_link[h];
+    gq3 best_cl = in_cl[h], best_xl = in_xl[h];
+    const unsigned long long pk = s_pkey[h * 256 + tid];
     if (pk != 0ull) {
       const int e = (int)(pk & 0xffffull);
       const float dis = s_ecl[e * 4 + 3];
@@ -323,7 +368,7 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
         best_xl = gq_mk(s_ent[e].x, s_ent[e].y, s_ent[e].z);
       }
     }
-    const size_t o = (size_t)row * g.P + pt;
+    const size_t o = (size_t)row * g.P + pt[h];
     g.dis[o] = best_link >= 0 ? best_dis : -1e30f;
     if (best_link >= 0) {
       const float* T = s_link + best_link * 24;

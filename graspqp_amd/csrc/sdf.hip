@@ -92,10 +92,10 @@ __global__ void gq_sdf_bwd_kernel(const float* __restrict__ g, const float* __re
 
 #include "pen_dev.h"
 
-template <bool EVAL, int ECAP, int ICAP>
+template <bool EVAL, int ECAP, int ICAP, int PPT = 1>
 __global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
-  gq_pen_grid_body<EVAL, ECAP, ICAP>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
+  gq_pen_grid_body<EVAL, ECAP, ICAP, PPT>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
 }
 __global__ __launch_bounds__(256) void gq_pen_cells_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
@@ -531,6 +531,14 @@ static void gq_box_of(const float* fv, const int32_t* perm, int64_t a, int64_t b
 }
 
 static unsigned long long* gq_pen_dbg_ = nullptr;
+// Surface points per thread of the penetration query (gq_debug_set_pen_ppt: 0 = defaults, 1 / 2 forced).  Two points per
+// thread halve the wavefronts and share prologue, loop overhead and list phases: +1.5..2 % at 256 rows, where the query is
+// a role of stage A.  As a launch of its own beside the force-closure branch the same variant is much faster alone (167 ->
+// 124 us at 2048 rows) but holds 84 instead of 62 VGPRs per wavefront, and the iteration gets 18 % SLOWER -- the
+// stand-alone kernel keeps one point per thread.
+static int gq_pen_ppt_ = 0;
+int gq_pen_points_per_thread_() { return gq_pen_ppt_ == 1 ? 1 : 2; }          // fused (stage A role)
+static int gq_pen_points_per_thread_standalone_() { return gq_pen_ppt_ == 2 ? 2 : 1; }
 static int gq_pen_caps_ = 0;  // gq_debug_set_pen_caps: 0 = by launch size, 1 / 2 / 3 = 512 / 256 / 128 entries (A/B runs)
 static int gq_sdf_plain_mapping_ = 0;  // gq_debug_set_sdf_mapping(1): A/B switch for the XCD-aware query placement
 
@@ -649,6 +657,10 @@ extern "C" {
 // diagnostics: device pointer to 4 uint64 counters filled by gq_hand_pen_forward (NULL = off, the default)
 int gq_debug_set_sdf_topk(int topk) {
   gq_sdf_topk_ = (topk == 2 || topk == 4) ? topk : 0;
+  return GQ_OK;
+}
+int gq_debug_set_pen_ppt(int ppt) {
+  gq_pen_ppt_ = (ppt == 1 || ppt == 2) ? ppt : 0;
   return GQ_OK;
 }
 int gq_debug_set_pen_caps(int mode) {
@@ -930,6 +942,9 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     else if (caps == 2)
       hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 256, 2048>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L, 256, 2048),
                             (hipStream_t)stream, e0, e1, 0, a);
+    else if (gq_pen_points_per_thread_standalone_() == 2)
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP, 2>), dim3((unsigned)((a.P + 511) / 512), (unsigned)a.B),
+                            dim3(256), gq_pen_grid_lds_bytes(a.L, GQ_PG_ECAP, GQ_PG_ICAP, 2), (hipStream_t)stream, e0, e1, 0, a);
     else
       hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L),
                             (hipStream_t)stream, e0, e1, 0, a);

@@ -18,10 +18,11 @@
 
 int gq_qp_stop_launch_(const float* resid, const float* mu, int B, int max_iter, float eps, int not_improved_lim,
                        float* runmin, int* kstar, int32_t* n_iter, void* stream);
+int gq_pen_points_per_thread_();  // sdf.hip: surface points per thread of the penetration query (gq_debug_set_pen_ppt)
 
 // STOP: the large-batch stop-rule epilogue is compiled in (its 70 extra registers would cost the small-batch
 // instantiation one wavefront per SIMD: 166 instead of 127 VGPRs)
-template <int NC, bool STOP>
+template <int NC, bool STOP, int PPT>
 __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcStepArgs f, GqPenArgs p, int gx, int nfc) {
   extern __shared__ char gq_lds[];
   const int b = (int)blockIdx.x;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcSt
     gq_pen_cells_body(p, b - nfc, gq_lds);
   } else {
     const int q = b - nfc;
-    gq_pen_grid_body<true>(p, q % gx, q / gx, gq_lds);
+    gq_pen_grid_body<true, GQ_PG_ECAP, GQ_PG_ICAP, PPT>(p, q % gx, q / gx, gq_lds);
   }
 }
 
@@ -137,7 +138,8 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
                        pen->Rg, nullptr, pen->link, pen->gvec, pen->link_wrench, pen->gRt, pen->dis, pen->w_pen, pen->e_pen,
                        pen->span, pen->span_acc, &pb);
   if (rc) return rc;
-  const int gx = pen->grid ? 0 : (p.P + 255) / 256;  // 0: the link-driven query, one block per row
+  const int ppt = gq_pen_points_per_thread_();
+  const int gx = pen->grid ? 0 : (p.P + 256 * ppt - 1) / (256 * ppt);  // 0: the link-driven query, one block per row
   const bool two = f.nz > GQ_WAVE;
   GqSpenRole sp{};
   int n_sp = 0;
@@ -156,18 +158,24 @@ int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* strea
     n_sp = (f.B + 3) / 4;
   }
   const int nfc = (f.B + GQ_HEAD_ROWS - 1) / GQ_HEAD_ROWS;
-  const size_t lds_a = std::max(pen->grid ? gq_pen_cells_lds_bytes(p.L, p.P) : gq_pen_grid_lds_bytes(p.L),
+  const size_t lds_a = std::max(pen->grid ? gq_pen_cells_lds_bytes(p.L, p.P) : gq_pen_grid_lds_bytes(p.L, GQ_PG_ECAP, GQ_PG_ICAP, ppt),
                                 (size_t)GQ_HEAD_ROWS * f.n * 6 * sizeof(float) + GQ_HEAD_LDS_WORDS * sizeof(unsigned));
   const size_t lds_b = std::max(std::max(gq_pen_bwd_lds_bytes(), (size_t)f.nz * 3 * sizeof(float)),
                                 n_sp ? (size_t)4 * ((size_t)sp.h.S * 16 + 512) : (size_t)0);
   const dim3 grid_a((unsigned)(nfc + (pen->grid ? 1 : gx) * p.B)), grid_b((unsigned)(2 * f.B + n_sp)), block(256);
+#define GQ_STAGE_A(NCV, STOPV)                                                                                        \
+  do {                                                                                                                \
+    if (ppt == 2) hipLaunchKernelGGL((gq_stage_a_kernel<NCV, STOPV, 2>), grid_a, block, lds_a, st, f, p, gx, nfc);    \
+    else hipLaunchKernelGGL((gq_stage_a_kernel<NCV, STOPV, 1>), grid_a, block, lds_a, st, f, p, gx, nfc);             \
+  } while (0)
   if (f.agg) {
-    if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2, true>), grid_a, block, lds_a, st, f, p, gx, nfc);
-    else hipLaunchKernelGGL((gq_stage_a_kernel<1, true>), grid_a, block, lds_a, st, f, p, gx, nfc);
+    if (two) GQ_STAGE_A(2, true);
+    else GQ_STAGE_A(1, true);
   } else {
-    if (two) hipLaunchKernelGGL((gq_stage_a_kernel<2, false>), grid_a, block, lds_a, st, f, p, gx, nfc);
-    else hipLaunchKernelGGL((gq_stage_a_kernel<1, false>), grid_a, block, lds_a, st, f, p, gx, nfc);
+    if (two) GQ_STAGE_A(2, false);
+    else GQ_STAGE_A(1, false);
   }
+#undef GQ_STAGE_A
   GQ_LAUNCH_CHECK();
   const bool fused_stop = f.B <= 4 * GQ_WAVE && f.max_iter <= 16;
   if (!fused_stop && !f.agg) {

@@ -322,6 +322,9 @@ int gq_debug_set_sdf_topk(int topk);
 /* LDS list capacities of the stand-alone hand-penetration query: 0 = by launch size (default), 1 / 2 / 3 = 512 / 256 /
  * 128 entries per block (A/B runs; results do not depend on it).                                                  */
 int gq_debug_set_pen_caps(int mode);
+/* surface points per thread of the hand-penetration query: 0 = defaults (2 as a role of gq_fc_pen_step, 1 in
+ * gq_hand_pen_forward), 1 / 2 forced for both (A/B runs; results do not depend on it).                              */
+int gq_debug_set_pen_ppt(int ppt);
 /* grad_dis (B,P) = upstream d E / d dis.  grad_dis == NULL selects the fused E_pen form: the weights are
  * w_pen * [dis > 0] and e_pen (B) = sum_j relu(dis_j) is written as well (core/energy.py:59-61).
  * span / span_acc (optional): the 64 x {min start, max end} shards filled by gq_hand_pen_forward are folded into

@@ -327,6 +327,41 @@ def test_hand_penetration_item_list_overflow(gq):
     assert big.mean() < 2e-3, big.mean()
 
 
+@pytest.mark.parametrize("scene", ["bench", "deep"])
+def test_penetration_query_two_points_per_thread_equals_one(gq, scene):
+    """gq_pen_grid_body with two surface points per thread (the default of the fused stage-A role) against one point per
+    thread (the default of the stand-alone launch): dis bit for bit -- the list phases are order-independent and overflow
+    is ranked inline with the same arithmetic.  2500 points: the last block of a row is ragged in both forms."""
+    from bench import make_initial_state
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+
+    spec = get_hand_spec("allegro")
+    n_obj, be, P = 2, 24, 2500
+    fvs = [meshes.superquadric(o) for o in range(n_obj)]
+    sps = [meshes.surface_points(f, P, oversample=4, seed=42) for f in fvs]
+    hp, idx = zip(*[make_initial_state(spec, f, be, 12, 1000 + o) for o, f in enumerate(fvs)])
+    hp, idx = torch.cat(hp), torch.cat(idx)
+    if scene == "deep":
+        hp[:, :3] *= 0.3  # the hand well inside the object: many entries per block, list overflow
+    else:
+        hp[::5, :3] *= 0.5
+    hm = HandModel(spec, "cuda")
+    om = ObjectModel(batch_size_each=be, num_samples=P)
+    om.initialize_from_meshes(fvs, surface_points_list=sps)
+    hm.set_parameters(hp.cuda(), idx.cuda())
+    outs = []
+    try:
+        for ppt in (1, 2):
+            gq.C.call("gq_debug_set_pen_ppt", ppt)
+            outs.append(hm.cal_distance(om.surface_points_each, penetration_only=1).clone())
+            torch.cuda.synchronize()
+    finally:
+        gq.C.call("gq_debug_set_pen_ppt", 0)
+    assert (outs[0] > 0).sum() > 0, "scene must contain penetrating points"
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("scene", ["bench", "deep", "fingertip"])
 @pytest.mark.parametrize("cells", [8, 4, 16])
 def test_link_driven_query_equals_point_driven(gq, scene, cells):

@@ -15,10 +15,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 LIB = os.path.join(ROOT, "graspqp_amd", "lib", "libgraspqp_hip.so")
 
 BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
-    "gq_stage_a_kernel<1, false>": (128, 0),   # config 2: fc head + penetration query, 4 wavefronts per SIMD
-    "gq_stage_a_kernel<1, true>": (128, 32),    # 257..511 rows in one grid: with the stop-rule epilogue, capped
+    "gq_stage_a_kernel<1, false, 2>": (128, 0),   # config 2: fc head + penetration query, 4 wavefronts per SIMD
+    "gq_stage_a_kernel<1, true, 2>": (128, 32),    # 257..511 rows in one grid: with the stop-rule epilogue, capped
     "gq_sdf_wave_kernel<4>": (128, 16),            # capped by __launch_bounds__(256, 4)
-    "gq_pen_grid_kernel<true, 512, 4096>": (64, 0),
+    "gq_pen_grid_kernel<true, 512, 4096, 1>": (64, 0),
     "gq_fc_head_kernel<1>": (128, 0),
     "gq_fc_head_stop_kernel<1>": (128, 32),     # large batches: capped (4 wavefronts per SIMD beside the other branch); 5 words spill
     "gq_fk_backward_kernel": (128, 0),
@@ -44,4 +44,4 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert r["scratch"] <= smax, (name, r)
     spilled = {k: v["scratch"] for k, v in res.items() if v["scratch"] > 0}
     assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel<4>", "gq_fc_head_stop_kernel<1>",
-                            "gq_stage_a_kernel<1, true>", "gq_fc_tail_kernel<1, 0>"}, f"new register spills: {spilled}"
+                            "gq_stage_a_kernel<1, true, 2>", "gq_stage_a_kernel<1, true, 1>", "gq_fc_tail_kernel<1, 0>"}, f"new register spills: {spilled}"

@@ -124,6 +124,11 @@ class HandSpec:
     cand_pos: np.ndarray = None  # (C,3) link frame
     cand_nrm: np.ndarray = None  # (C,3) link frame
     cand_link: np.ndarray = None  # (C,) int32 mesh-link index
+    # contact patches the reference samples its candidates from (contact_points.json -> [mesh file, n],
+    # hand_model.py:269-296): triangles in the link frame (visual scale and offset applied); only read when a grasp type
+    # asks for MORE candidates on a link than the reference's dump holds
+    patch_verts: np.ndarray = None  # (sumP,3,3) float32
+    patch_face_offset: np.ndarray = None  # (L+1,) int32 prefix sum into patch_verts
     # ---- penetration spheres ---------------------------------------------------------------------
     sphere: np.ndarray = None  # (S,4) xyz r, link frame
     sphere_link: np.ndarray = None  # (S,) int32 mesh-link index (non-decreasing)
@@ -192,19 +197,23 @@ class HandSpec:
         if grasp_type not in data:
             raise ValueError(f"grasp type {grasp_type} not found in eigengrasps.json. Available grasp types are {list(data.keys())}")
         links = data[grasp_type]
-        keep = []
+        keep, extra = [], []
         for li, lname in enumerate(self.link_names):
             idx = np.nonzero(self.cand_link == li)[0]
             if lname not in links or len(idx) == 0:
                 continue
             k = int(links[lname].get("n_points", len(idx))) if isinstance(links[lname], dict) else len(idx)
             if k > len(idx):
-                raise NotImplementedError(f"{self.name}/{grasp_type}: {k} contact candidates requested on {lname}, the "
-                                          f"reference's dump holds {len(idx)}")
+                extra.append((li, *self._more_candidates(li, idx, k)))
             keep.append(idx[:k])
         s = copy.copy(self)
         keep = np.concatenate(keep) if keep else np.zeros(0, dtype=np.int64)
         s.cand_pos, s.cand_nrm, s.cand_link = self.cand_pos[keep], self.cand_nrm[keep], self.cand_link[keep]
+        for li, pos, nrm in extra:  # the new candidates follow the dumped ones of their link (candidates stay link-sorted)
+            at = int(np.searchsorted(s.cand_link, li, side="right"))
+            s.cand_pos = np.concatenate([s.cand_pos[:at], pos, s.cand_pos[at:]]).astype(np.float32)
+            s.cand_nrm = np.concatenate([s.cand_nrm[:at], nrm, s.cand_nrm[at:]]).astype(np.float32)
+            s.cand_link = np.concatenate([s.cand_link[:at], np.full(len(pos), li, np.int32), s.cand_link[at:]]).astype(np.int32)
         s.contact_links = links
         ds = self.default_state.copy()
         rules = {  # hand_model.py:550-589: (substrings of the fingers to fold away, joint-name parts that are left alone)
@@ -221,6 +230,33 @@ class HandSpec:
         s.grasp_type = grasp_type
         return s
 
+    def _more_candidates(self, li: int, have: np.ndarray, k: int):
+        """k - len(have) further contact candidates on mesh link ``li`` (reference hand_model.py:269-296,333-335: 1000 even
+        surface samples of the link's contact patch -> farthest-point sampling -> normal of the closest link-mesh face).
+        The reference's sample stream (trimesh + numpy seed 42) cannot be reproduced here, so the candidates its dump
+        holds stay the first ones -- farthest-point sequences are nested, they ARE the reference's first len(have) -- and
+        the sequence is continued over a natively sampled pool (parity unpinned for the added points)."""
+        from ..utils import meshes
+
+        if self.patch_face_offset is None or self.patch_face_offset[li + 1] == self.patch_face_offset[li]:
+            raise NotImplementedError(f"{self.name}: {k} contact candidates requested on {self.link_names[li]}, the "
+                                      f"reference's dump holds {len(have)} and the spec has no contact patch for the link")
+        patch = self.patch_verts[self.patch_face_offset[li]:self.patch_face_offset[li + 1]]
+        pool = meshes.sample_surface(patch, 1000, seed=42)
+        got = self.cand_pos[have].astype(np.float64)
+        dist = ((pool[:, None] - got[None]) ** 2).sum(-1).min(1) if len(got) else np.full(len(pool), np.inf)
+        new = []
+        for _ in range(k - len(have)):
+            j = int(np.argmax(dist))
+            new.append(pool[j])
+            dist = np.minimum(dist, ((pool - pool[j]) ** 2).sum(1))
+        new = np.asarray(new)
+        fv = self.link_faces(li).astype(np.float64)
+        _, _, fi = meshes.closest_face(new, fv)
+        n = np.cross(fv[fi, 1] - fv[fi, 0], fv[fi, 2] - fv[fi, 0])
+        n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+        return new.astype(np.float32), n.astype(np.float32)
+
     def link_faces(self, l: int) -> np.ndarray:
         return self.face_verts[self.link_face_offset[l] : self.link_face_offset[l + 1]]
 
@@ -232,6 +268,8 @@ class HandSpec:
                 out[f.name] = np.array(v, dtype=np.str_)
             elif isinstance(v, str):
                 out[f.name] = np.array(v, dtype=np.str_)
+            elif v is None:
+                continue
             else:
                 out[f.name] = v
         np.savez_compressed(path, **out)
@@ -241,6 +279,8 @@ class HandSpec:
         z = np.load(path, allow_pickle=False)
         kw = {}
         for f in fields(cls):
+            if f.name not in z.files and f.name in ("patch_verts", "patch_face_offset"):
+                continue  # specs written before the contact patches were stored
             v = z[f.name]
             if f.name in ("frame_names", "joint_names", "link_names", "full_joint_names"):
                 kw[f.name] = [str(s) for s in v.tolist()]
@@ -276,6 +316,8 @@ def build_hand_spec(
     joint_filter: Optional[List[str]] = None,
     coupling: Optional[Dict[str, tuple]] = None,
     eigengrasps_path: Optional[str] = None,
+    contact_points_path: Optional[str] = None,
+    contact_mesh_root: Optional[str] = None,
 ) -> HandSpec:
     """URDF + OBJ meshes + JSON side files -> HandSpec (reference hand_model.py:395-696)."""
     root = ET.parse(urdf_path).getroot()
@@ -327,6 +369,8 @@ def build_hand_spec(
     # ---- geometry per link (hand_model.py:215-257) ------------------------------------------------
     pen_pts = json.load(open(penetration_points_path)) if penetration_points_path else {}
     cinfo = json.load(open(contact_infos_path)) if contact_infos_path else {}
+    cpts = json.load(open(contact_points_path)) if contact_points_path and os.path.exists(contact_points_path) else {}
+    patch_chunks, patch_off = [], [0]
 
     link_names, link_frame, face_chunks, face_off = [], [], [], [0]
     cand_pos, cand_nrm, cand_link = [], [], []
@@ -345,7 +389,7 @@ def build_hand_spec(
         else:
             elems = col
         tris = []
-        last_T = np.eye(4)
+        last_T, last_scale = np.eye(4), np.ones(3)
         for e in elems:
             g = e.find("geometry")
             m = g.find("mesh") if g is not None else None
@@ -364,7 +408,7 @@ def build_hand_spec(
             T = _origin(e)
             tv = tv @ T[:3, :3].T + T[:3, 3]
             tris.append(tv)
-            last_T = T
+            last_T, last_scale = T, scale
         li = len(link_names)
         link_names.append(lname)
         link_frame.append(fi)
@@ -377,6 +421,15 @@ def build_hand_spec(
             cand_pos.append(cp)
             cand_nrm.append(cn)
             cand_link += [li] * len(cp)
+        pt = []
+        for cand in (cpts.get(lname) or []):  # [mesh file, n]: the patch the reference samples n candidates from
+            if isinstance(cand, list) and len(cand) == 2 and isinstance(cand[0], str):
+                pm = os.path.normpath(os.path.join(contact_mesh_root or mesh_path, cand[0]))
+                if os.path.exists(pm):
+                    pv = load_obj_triangles(pm) * last_scale
+                    pt.append(pv @ last_T[:3, :3].T + last_T[:3, 3])
+        patch_chunks.append(np.concatenate(pt, 0) if pt else np.zeros((0, 3, 3)))
+        patch_off.append(patch_off[-1] + len(patch_chunks[-1]))
         if lname in pen_pts and len(pen_pts[lname]) > 0:
             pk = np.asarray(pen_pts[lname], dtype=np.float64)
             if pk.shape[-1] == 4:
@@ -463,6 +516,8 @@ def build_hand_spec(
         cand_pos=f32(np.concatenate(cand_pos, 0) if cand_pos else np.zeros((0, 3))),
         cand_nrm=f32(np.concatenate(cand_nrm, 0) if cand_nrm else np.zeros((0, 3))),
         cand_link=i32(cand_link),
+        patch_verts=f32(np.concatenate(patch_chunks, 0).reshape(-1, 3, 3) if patch_chunks else np.zeros((0, 3, 3))),
+        patch_face_offset=i32(patch_off),
         sphere=f32(np.concatenate(sphere, 0) if sphere else np.zeros((0, 4))),
         sphere_link=i32(sphere_link),
         node_parent=i32(node_parent),

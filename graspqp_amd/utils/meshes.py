@@ -179,3 +179,45 @@ def area_cdf(face_verts: np.ndarray) -> np.ndarray:
     area = 0.5 * np.linalg.norm(np.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0]), axis=1)
     c = np.cumsum(area)
     return c / c[-1]
+
+
+def closest_face(points: np.ndarray, face_verts: np.ndarray):
+    """Closest point of a triangle soup to every query: (closest (N,3), squared distance (N,), face index (N,)), float64.
+    Asset set-up only (the contact normals of re-sampled candidates, reference hand_model.py:333-335 ->
+    ``trimesh.proximity.closest_point``); the per-iteration queries are the HIP kernels.  Region walk of Ericson,
+    Real-Time Collision Detection 5.1.5, vectorised over (N, F); ties go to the smallest face index."""
+    p = np.asarray(points, dtype=np.float64).reshape(-1, 1, 3)
+    fv = np.asarray(face_verts, dtype=np.float64)
+    a, b, c = fv[None, :, 0], fv[None, :, 1], fv[None, :, 2]
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        den = va + vb + vc
+        v_in, w_in = vb / den, vc / den
+        t_ab, t_ac = d1 / (d1 - d3), d2 / (d2 - d6)
+        t_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+    # barycentric (v, w) of the closest point: a + v ab + w ac; later assignments have lower priority
+    v, w = v_in, w_in
+    bc = (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0)
+    v, w = np.where(bc, 1 - t_bc, v), np.where(bc, t_bc, w)
+    e_ac = (vb <= 0) & (d2 >= 0) & (d6 <= 0)
+    v, w = np.where(e_ac, 0.0, v), np.where(e_ac, t_ac, w)
+    vert_c = (d6 >= 0) & (d5 <= d6)
+    v, w = np.where(vert_c, 0.0, v), np.where(vert_c, 1.0, w)
+    e_ab = (vc <= 0) & (d1 >= 0) & (d3 <= 0)
+    v, w = np.where(e_ab, t_ab, v), np.where(e_ab, 0.0, w)
+    vert_b = (d3 >= 0) & (d4 <= d3)
+    v, w = np.where(vert_b, 1.0, v), np.where(vert_b, 0.0, w)
+    vert_a = (d1 <= 0) & (d2 <= 0)
+    v, w = np.where(vert_a, 0.0, v), np.where(vert_a, 0.0, w)
+    v, w = np.nan_to_num(v), np.nan_to_num(w)  # degenerate faces collapse onto corner a
+    q = a + v[..., None] * ab + w[..., None] * ac
+    d2q = ((p - q) ** 2).sum(-1)
+    fi = np.argmin(d2q, axis=1)
+    n = np.arange(len(fi))
+    return q[n, fi], d2q[n, fi], fi

@@ -237,3 +237,60 @@ def test_coupled_hands_and_grasp_types():
     with pytest.raises(ValueError):
         get_hand_spec("allegro", grasp_type="no_such_type")
     assert get_hand_spec("allegro", grasp_type="all").n_contact_candidates == 92
+
+
+def test_contact_patches_and_grasp_types_asking_for_more_candidates():
+    """hand_model.py:269-296,333-335: candidates are farthest-point samples of a link's contact patch, their normals the
+    normals of the closest link-mesh face.  (i) The patches baked into the specs are pinned by the reference's own dump:
+    every dumped candidate lies on its link's patch.  (ii) A grasp type that wants more candidates than the dump holds
+    (shadow_hand / ability_hand "pinch": 16 on two links) keeps the dumped ones first and continues the farthest-point
+    sequence on the patch (parity unpinned for the added points: the reference's sample stream needs trimesh)."""
+    import sys
+
+    from graspqp_amd.hands import AVAILABLE_HANDS, get_hand_spec
+    from graspqp_amd.utils import meshes
+
+    for h in AVAILABLE_HANDS:
+        s = get_hand_spec(h)
+        for li in range(s.n_links):
+            idx = np.nonzero(s.cand_link == li)[0]
+            pv = s.patch_verts[s.patch_face_offset[li]:s.patch_face_offset[li + 1]]
+            assert (len(idx) == 0) == (len(pv) == 0), (h, s.link_names[li])
+            if len(idx):
+                _, d2, _ = meshes.closest_face(s.cand_pos[idx], pv)
+                assert np.sqrt(d2.max()) < 1e-7, (h, s.link_names[li])
+    n_grown = 0
+    for h, per_link in (("shadow_hand", 16), ("ability_hand", 16)):
+        base, sub = get_hand_spec(h), get_hand_spec(h, grasp_type="pinch")
+        assert sub.n_contact_candidates == 2 * per_link and np.all(np.diff(sub.cand_link) >= 0)
+        for li in np.unique(sub.cand_link):
+            i_b, i_s = np.nonzero(base.cand_link == li)[0], np.nonzero(sub.cand_link == li)[0]
+            k0 = min(len(i_b), per_link)
+            assert len(i_s) == per_link
+            np.testing.assert_array_equal(sub.cand_pos[i_s][:k0], base.cand_pos[i_b][:k0])
+            np.testing.assert_array_equal(sub.cand_nrm[i_s][:k0], base.cand_nrm[i_b][:k0])
+            new_p, new_n = sub.cand_pos[i_s][k0:], sub.cand_nrm[i_s][k0:]
+            if len(new_p) == 0:
+                continue  # the dump already holds as many as the grasp type wants on this link
+            n_grown += 1
+            pv = base.patch_verts[base.patch_face_offset[li]:base.patch_face_offset[li + 1]]
+            assert np.sqrt(meshes.closest_face(new_p, pv)[1].max()) < 1e-6  # on the patch
+            np.testing.assert_allclose(np.linalg.norm(new_n, axis=1), 1.0, atol=1e-6)
+            # normals = normal of the closest link-mesh face, cross-checked with the oracle's closest-point search
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+            import torch
+            from ref_cpu import sdf as osdf
+
+            fv = torch.tensor(base.link_faces(li), dtype=torch.float64)
+            d2, sgn, nrm, closest = osdf.compute_sdf(torch.tensor(new_p, dtype=torch.float64), fv)
+            q, d2m, fi = meshes.closest_face(new_p, base.link_faces(li))
+            np.testing.assert_allclose(d2m, d2.numpy(), atol=1e-12)
+            fvn = base.link_faces(li).astype(np.float64)
+            fn = np.cross(fvn[fi, 1] - fvn[fi, 0], fvn[fi, 2] - fvn[fi, 0])
+            fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+            np.testing.assert_allclose(new_n, fn, atol=1e-6)
+            # farthest-point property: every added point is at least as far from the earlier ones as the dumped set's spacing / 2
+            P = sub.cand_pos[i_s].astype(np.float64)
+            D = np.linalg.norm(P[:, None] - P[None], axis=-1) + 1e9 * np.eye(len(P))
+            assert D.min() > 1e-3
+    assert n_grown == 3  # shadow_hand: both distal links; ability_hand: index_L2

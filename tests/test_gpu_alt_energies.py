@@ -216,7 +216,7 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
 # coupled-joint hands and grasp-type subsets
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("hand_name,grasp_type", [("ability_hand", None), ("panda", None), ("allegro", "pinch"),
-                                                  ("ability_hand", "precision")])
+                                                  ("ability_hand", "precision"), ("shadow_hand", "pinch")])
 def test_coupled_hands_and_grasp_types_whole_iteration(gq, hand_name, grasp_type):
     """Energy + gradient of the whole composition for hands whose tree joints follow fewer actuated ones (ability_hand:
     q2 = 1.0585 q1 on four fingers; panda: both fingers on one value -- reference hands/ability_hand.py, panda.py) and

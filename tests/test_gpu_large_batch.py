@@ -46,6 +46,7 @@ def _rel(a, b, floor=1e-12):
     ("shadow_hand", 16, 4, 8, 512),   # configs[2]: 8 meshes x 512 = 4096 rows, nz = 64
     ("robotiq3", 12, 8, 8, 1024),     # configs[4] share: 8 meshes x 1024 = 8192 rows, 8-edge cones, nz = 96
     ("allegro", 12, 4, 3, 171),       # 513 rows: the last force-closure head block holds ONE row (stop-rule epilogue)
+    ("robotiq3", 12, 8, 32, 1024),    # configs[4] per rank at its stated size: 32 meshes x 1024 = 32 768 rows
 ])
 def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     from bench import make_initial_state

@@ -475,7 +475,12 @@ __global__ void gq_occ_faces_kernel(const GqFace* __restrict__ rec, const int32_
     for (int iy = i0[1]; iy <= i1[1]; ++iy) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], xm);
 }
 
-// one thread per voxel centre of mesh blockIdx.y: brute-force closest face -> inside?  (32768 centres per mesh)
+// one thread per voxel of mesh blockIdx.y: inside?  (32768 voxels per mesh).  "Inside" is TorchSDF's rule -- the sign of
+// the closest face -- which is not constant over a voxel that touches no face: next to edges whose first-minimum face
+// looks away, and inside links whose mesh is several shells (shadow hand), it flips over a fraction of a millimetre.  The
+// voxel is therefore probed at its centre AND its eight corners (brute force over the faces, setup time only) and marked
+// when any probe is inside: a marked voxel only means "evaluate the point itself", so probing more can never make a
+// result wrong, it only leaves fewer points to the "unmarked = outside" shortcut (deviation iv).
 __global__ __launch_bounds__(256) void gq_occ_centres_kernel(const GqFace* __restrict__ rec,
                                                              const int32_t* __restrict__ off,
                                                              const float* __restrict__ aabb,
@@ -484,23 +489,25 @@ __global__ __launch_bounds__(256) void gq_occ_centres_kernel(const GqFace* __res
   const int v = blockIdx.x * blockDim.x + threadIdx.x;  // 0..32767
   const int ix = v & 31, iy = (v >> 5) & 31, iz = v >> 10;
   const float* bb = aabb + m * 8;
-  const gq3 p = gq_mk(bb[0] + ((float)ix + 0.5f) / bb[3], bb[1] + ((float)iy + 0.5f) / bb[7],
-                      bb[2] + ((float)iz + 0.5f) / invz[m]);
   const int f0 = off[m], f1 = off[m + 1];
-  float best = GQ_INF_F;
-  int bi = -1;
-  for (int f = f0; f < f1; ++f) {
-    const GqFace fc = rec[f];
-    const float d2 = gq_tri_rank(fc, p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
-    if (d2 < best) {
-      best = d2;
-      bi = f;
+  bool inside = false;
+  for (int s = 0; s < 9 && !inside; ++s) {  // s = 0: centre; 1..8: corners
+    const float ox = s == 0 ? 0.5f : (float)((s - 1) & 1), oy = s == 0 ? 0.5f : (float)(((s - 1) >> 1) & 1),
+                oz = s == 0 ? 0.5f : (float)(((s - 1) >> 2) & 1);
+    const gq3 p = gq_mk(bb[0] + ((float)ix + ox) / bb[3], bb[1] + ((float)iy + oy) / bb[7], bb[2] + ((float)iz + oz) / invz[m]);
+    float best = GQ_INF_F;
+    int bi = -1;
+    for (int f = f0; f < f1; ++f) {
+      const GqFace fc = rec[f];
+      const float d2 = gq_tri_rank(fc, p - gq_mk(fc.r0.x, fc.r0.y, fc.r0.z));
+      if (d2 < best) {
+        best = d2;
+        bi = f;
+      }
     }
+    if (bi >= 0) inside = gq_tri_finish(rec[bi], p).sign < 0;
   }
-  if (bi >= 0) {
-    const GqSdfOut o = gq_tri_finish(rec[bi], p);
-    if (o.sign < 0) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], 1u << ix);
-  }
+  if (inside) atomicOr(&occ[(size_t)m * 1024 + iz * 32 + iy], 1u << ix);
 }
 
 #include <algorithm>
@@ -753,8 +760,8 @@ int gq_meshset_create(const float* face_verts_host, const int32_t* face_offset_h
 }
 
 // Occupancy grid of every mesh (setup-time).  Voxel (ix,iy,iz) of the 32^3 grid over the mesh AABB is marked when
-// (a) the bounding box of some face overlaps it, or (b) its centre is inside the mesh (sign of the closest face).
-// An unmarked voxel does not touch the surface, so it lies entirely on one side, and (b) says it is outside.
+// (a) the bounding box of some face overlaps it (+- one voxel), or (b) its centre or one of its corners is inside the mesh
+// (sign of the closest face).  An unmarked voxel does not touch the surface and nine probes of it are outside.
 int gq_meshset_build_occupancy(gqMeshSet* ms) {
   GQ_REQUIRE(ms, "meshset_build_occupancy: null");
   if (ms->occ_dev) return GQ_OK;

@@ -74,13 +74,23 @@ struct GqPenArgs {
 
 // launch time span in 100 MHz s_memrealtime ticks, sharded 64 ways so the atomics of 1e3 blocks do not pile up on one
 // address: span[2*s] = min start, span[2*s+1] = max end of the blocks with (linear block id % 64) == s
+// -DGQ_BLOCK_TIMES (development builds only, tools/block_timeline.py): the span buffer is followed by eight words per
+// block -- start, end, end of scan / ranking / finish, entries | items << 32 -- so the caller passes 128 + 8 * blocks words
 __device__ __forceinline__ void gq_span_open(uint64_t* span, unsigned block_id) {
   const unsigned s = block_id & 63u;
-  atomicMin((unsigned long long*)&span[2 * s], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const unsigned long long t = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  atomicMin((unsigned long long*)&span[2 * s], t);
+#ifdef GQ_BLOCK_TIMES
+  span[128 + 8 * (size_t)block_id] = t;
+#endif
 }
 __device__ __forceinline__ void gq_span_close(uint64_t* span, unsigned block_id) {
   const unsigned s = block_id & 63u;
-  atomicMax((unsigned long long*)&span[2 * s + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  const unsigned long long t = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+  atomicMax((unsigned long long*)&span[2 * s + 1], t);
+#ifdef GQ_BLOCK_TIMES
+  span[128 + 8 * (size_t)block_id + 1] = t;
+#endif
 }
 
 // ---- penetration-only query with per-voxel candidate faces (the hot path of E_pen) -------------------------------
@@ -258,29 +268,27 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
         if (!((g.occ[(size_t)l * 1024 + iz * 32 + iy] >> ix) & 1u)) continue;
         continue;
       }
-      // (no look-up of the occupancy bit first: a voxel that is not occupied has an empty candidate list -- one dependent
-      // round trip less)
-      const size_t v = (size_t)l * 32768 + (size_t)(iz * 1024 + iy * 32 + ix);
-      const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
-      if (len == 0u) continue;
-      if (g.dbg) atomicAdd(&s_cnt[3], (int)len);
+      // No global memory in this loop: the pair becomes an entry that remembers its voxel; the candidate lists of all
+      // entries of the block are looked up afterwards, by all threads at once (A2).  A lane inside k link boxes used to
+      // wait for k dependent look-ups here, and with it its whole wavefront (the scan was 4 .. 14 us of a block's 5 .. 18).
+      const uint32_t vox = (uint32_t)(iz * 1024 + iy * 32 + ix);
       const int e = atomicAdd(&s_cnt[0], 1);
-      int ib = ICAP;
-      if (e < ECAP && len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
-      if (e < ECAP && ib + (int)len <= ICAP) {
+      if (e < ECAP) {
         GqPgEntry en;
         en.x = xl.x; en.y = xl.y; en.z = xl.z;
-        en.c0 = c0;
+        en.c0 = vox;
         en.pt = (uint16_t)(h * 256 + tid);
         en.link = (uint16_t)l;
         s_ent[e] = en;
-        s_ekey[e] = ~0ull;
-        for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
-      } else {  // no room: rank the candidates here
-        if (g.dbg) atomicAdd(&s_cnt[2], 1);
-        if (e < ECAP) s_ent[e].c0 = 0xffffffffu;  // entry slot unused
-        // the part of the item list this entry reserved but does not use must not be read as items
-        for (int i = ib; i < ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
+      } else {  // no entry slot left: look the candidates up and rank them here
+        const size_t v = (size_t)l * 32768 + (size_t)vox;
+        const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
+        if (len == 0u) continue;
+        if (g.dbg) {
+          atomicAdd(&s_cnt[3], (int)len);
+          atomicAdd(&s_cnt[2], 1);
+          atomicAdd(&g.dbg[4], 1ull);
+        }
         const int f0 = g.off[l];
         float bd = GQ_INF_F;
         unsigned bo = 0xffffffffu;
@@ -308,13 +316,58 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     }
   }
   __syncthreads();
+  // ---- A2: candidate lists of the entries -- independent look-ups, one round trip for the whole block ----------------
+  {
+    const int n_pre = min(s_cnt[0], ECAP);
+    for (int e = tid; e < n_pre; e += 256) {
+      const GqPgEntry en = s_ent[e];
+      const size_t v = (size_t)en.link * 32768 + (size_t)en.c0;
+      const uint32_t c0 = g.cand_off[v], len = g.cand_off[v + 1] - c0;
+      if (len == 0u) {  // voxel neither touches a face nor is inside: the point is outside this link
+        s_ent[e].c0 = 0xffffffffu;
+        continue;
+      }
+      if (g.dbg) {
+        atomicAdd(&s_cnt[3], (int)len);
+        atomicAdd(&g.dbg[4], 1ull);
+      }
+      s_ent[e].c0 = c0;
+      int ib = ICAP;
+      if (len <= 0xffffu) ib = atomicAdd(&s_cnt[1], (int)len);
+      if (ib + (int)len <= ICAP) {
+        s_ekey[e] = ~0ull;
+        for (uint32_t j = 0; j < len; ++j) s_item[ib + j] = ((uint32_t)e << 16) | j;
+      } else {  // no room in the item list: rank the candidates here; the entry is finished in C like any other
+        if (g.dbg) atomicAdd(&s_cnt[2], 1);
+        // the part of the item list this entry reserved but does not use must not be read as items
+        for (int i = ib; i < ICAP && i < ib + (int)len; ++i) s_item[i] = 0xffffffffu;
+        const int f0 = g.off[en.link];
+        unsigned long long key = ~0ull;
+        for (uint32_t j = 0; j < len; ++j) {
+          const unsigned fl = g.cand_idx[c0 + j];
+          const GqFace fc = g.rec[f0 + (int)fl];
+          const float d2 = gq_tri_rank(fc, gq_mk(en.x - fc.r0.x, en.y - fc.r0.y, en.z - fc.r0.z));
+          const unsigned orig = (unsigned)__float_as_int(fc.r5.z) - (unsigned)f0;
+          const unsigned long long k = gq_rank_key(d2, orig, fl);
+          key = k < key ? k : key;
+        }
+        s_ekey[e] = key;
+      }
+    }
+  }
+  __syncthreads();
   if (g.dbg && tid == 0) {
-    atomicAdd(&g.dbg[4], (unsigned long long)s_cnt[0]);
     atomicAdd(&g.dbg[5], (unsigned long long)s_cnt[3]);
     atomicAdd(&g.dbg[6], (unsigned long long)s_cnt[2]);
     atomicAdd(&g.dbg[7], 1ull);
   }
   const int n_ent = min(s_cnt[0], ECAP), n_item = min(s_cnt[1], ICAP);
+#ifdef GQ_BLOCK_TIMES
+  if (g.span && tid == 0) {
+    g.span[128 + 8 * (size_t)block_id + 2] = __builtin_amdgcn_s_memrealtime();
+    g.span[128 + 8 * (size_t)block_id + 5] = (uint64_t)(unsigned)s_cnt[0] | ((uint64_t)(unsigned)s_cnt[1] << 32);
+  }
+#endif
   // ---- B: one (entry, candidate) ranking per thread and step ----------------------------------------------------
   for (int i = tid; i < n_item; i += 256) {
     const uint32_t it = s_item[i];
@@ -329,10 +382,13 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     atomicMin(&s_ekey[e], gq_rank_key(d2, orig, fl));
   }
   __syncthreads();
+#ifdef GQ_BLOCK_TIMES
+  if (g.span && tid == 0) g.span[128 + 8 * (size_t)block_id + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- C: finish the winner of every entry ----------------------------------------------------------------------
   for (int e = tid; e < n_ent; e += 256) {
     const GqPgEntry en = s_ent[e];
-    if (en.c0 == 0xffffffffu) continue;  // was ranked inline
+    if (en.c0 == 0xffffffffu) continue;  // its voxel has no candidate faces: outside this link
     const int f = g.off[en.link] + (int)(s_ekey[e] & 0xffffull);
     const gq3 xl = gq_mk(en.x, en.y, en.z);
     const GqSdfOut o = gq_tri_finish(g.rec[f], xl);
@@ -347,6 +403,9 @@ __device__ __forceinline__ void gq_pen_grid_body(const GqPenArgs& g, int bx, int
     }
   }
   __syncthreads();
+#ifdef GQ_BLOCK_TIMES
+  if (g.span && tid == 0) g.span[128 + 8 * (size_t)block_id + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- D: outputs ---------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int h = 0; h < PPT; ++h) {

@@ -95,9 +95,11 @@ __device__ __forceinline__ void gq_span_close(uint64_t* span, unsigned block_id)
 
 // ---- penetration-only query with per-voxel candidate faces (the hot path of E_pen) -------------------------------
 // One block = 256 surface points of one row, no global queues, no global atomics.
-//   A  every thread walks the links for its point: bounding sphere of the link box (LDS), link frame, AABB, occupancy
-//      bit of the 32^3 voxel.  Only 2e3 .. 3e4 of the 9e6 (point, link) pairs of a config-2 launch survive; a survivor
-//      becomes an ENTRY in LDS and its voxel's candidate faces become ITEMS (entry, j) in LDS.
+//   A  every thread walks the links for its point: bounding sphere of the link box (LDS), link frame, AABB, voxel of the
+//      32^3 grid -- no global memory.  Only 2e3 .. 3e4 of the 9e6 (point, link) pairs of a config-2 launch survive; a
+//      survivor becomes an ENTRY in LDS that remembers its voxel.
+//   A2 the block's threads share the entries: candidate list of the entry's voxel (independent look-ups, one round trip
+//      for the block); an empty list retires the entry, otherwise its candidate faces become ITEMS (entry, j) in LDS.
 //   B  the block's threads share the items evenly: one (point, face) ranking each, all lanes busy, independent gathers
 //      in flight; the minimum per entry is taken with a 64-bit LDS atomicMin on (distance, original face index, face),
 //      which is independent of the processing order.
@@ -105,8 +107,9 @@ __device__ __forceinline__ void gq_span_close(uint64_t* span, unsigned block_id)
 //      with a 64-bit LDS atomicMax on (dis, 255 - link, entry) -- the max over links with torch's first-index tie rule.
 //   D  the point's own thread writes dis (every point) and link / gradient (penetrating points only).
 // The candidate list of a voxel holds every face that is closest for SOME point of the voxel (gq_cand_kernel), so the
-// result equals the brute-force scan of the whole link mesh.  Entries / items beyond the LDS capacities are ranked
-// inline by the thread that found them (same arithmetic, just slower).
+// result equals the brute-force scan of the whole link mesh.  Entries beyond the LDS capacity are looked up and ranked
+// inline by the thread that found them, items beyond it by the thread that looked the entry up (same arithmetic, just
+// slower).
 #define GQ_PG_ECAP 512
 #define GQ_PG_ICAP 4096
 struct GqPgEntry {

@@ -95,7 +95,9 @@ __global__ void gq_sdf_bwd_kernel(const float* __restrict__ g, const float* __re
 template <bool EVAL, int ECAP, int ICAP, int PPT = 1>
 __global__ __launch_bounds__(256) void gq_pen_grid_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
-  gq_pen_grid_body<EVAL, ECAP, ICAP, PPT>(g, (int)blockIdx.x, (int)blockIdx.y, gq_lds);
+  // slice-major grid (x = row, y = slice block): the blocks dispatched last are those of the last, partly filled slice of
+  // every row rather than all slices of the last rows -- the late starters decide when the launch ends
+  gq_pen_grid_body<EVAL, ECAP, ICAP, PPT>(g, (int)blockIdx.y, (int)blockIdx.x, gq_lds);
 }
 __global__ __launch_bounds__(256) void gq_pen_cells_kernel(GqPenArgs g) {
   extern __shared__ char gq_lds[];
@@ -932,6 +934,7 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
   a.dbg = gq_pen_dbg_;
   a.patch = patch_spheres;
   const dim3 grid((unsigned)((a.P + 255) / 256), (unsigned)a.B);
+  const dim3 grid_sm((unsigned)a.B, (unsigned)((a.P + 255) / 256));  // gq_pen_grid_kernel: x = row, y = slice block
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timer) {  // gqTimer: the kernel's own start/stop timestamps (hipExtLaunchKernelGGL), not stream markers
     e0 = ((hipEvent_t*)timer)[0];
@@ -944,19 +947,19 @@ int gq_hand_pen_forward(const gqMeshSet* links, const float* surface_points, int
     // smallest ones overflow into inline ranking; so the large lists stay the default
     const int caps = gq_pen_caps_ ? gq_pen_caps_ : 1;
     if (caps == 3)
-      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 128, 1024>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L, 128, 1024),
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 128, 1024>), grid_sm, dim3(256), gq_pen_grid_lds_bytes(a.L, 128, 1024),
                             (hipStream_t)stream, e0, e1, 0, a);
     else if (caps == 2)
-      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 256, 2048>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L, 256, 2048),
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, 256, 2048>), grid_sm, dim3(256), gq_pen_grid_lds_bytes(a.L, 256, 2048),
                             (hipStream_t)stream, e0, e1, 0, a);
     else if (gq_pen_points_per_thread_standalone_() == 2)
-      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP, 2>), dim3((unsigned)((a.P + 511) / 512), (unsigned)a.B),
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP, 2>), dim3((unsigned)a.B, (unsigned)((a.P + 511) / 512)),
                             dim3(256), gq_pen_grid_lds_bytes(a.L, GQ_PG_ECAP, GQ_PG_ICAP, 2), (hipStream_t)stream, e0, e1, 0, a);
     else
-      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L),
+      hipExtLaunchKernelGGL((gq_pen_grid_kernel<true, GQ_PG_ECAP, GQ_PG_ICAP>), grid_sm, dim3(256), gq_pen_grid_lds_bytes(a.L),
                             (hipStream_t)stream, e0, e1, 0, a);
   } else if (penetration_only == 9 && a.occ && a.cand_off) {  // diagnostics: the scan without candidate evaluation
-    hipExtLaunchKernelGGL((gq_pen_grid_kernel<false, GQ_PG_ECAP, GQ_PG_ICAP>), grid, dim3(256), gq_pen_grid_lds_bytes(a.L),
+    hipExtLaunchKernelGGL((gq_pen_grid_kernel<false, GQ_PG_ECAP, GQ_PG_ICAP>), grid_sm, dim3(256), gq_pen_grid_lds_bytes(a.L),
                           (hipStream_t)stream, e0, e1, 0, a);
   } else if ((penetration_only == 1 || penetration_only == 3) && workspace != nullptr) {
     // queue-based, load-balanced path without candidate lists (see gq_pen_scan_kernel); 3 forces it for A/B tests

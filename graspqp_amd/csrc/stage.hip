@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcSt
   } else if (gx == 0) {  // link-driven query: one block per row (gqPenStepDesc.grid)
     gq_pen_cells_body(p, b - nfc, gq_lds);
   } else {
+    // slice-major: the blocks that are dispatched last -- the ones that have to wait for a free slot (four blocks per CU
+    // are resident, B/4 of the slots hold the fc rows) and so decide when the role ends -- are those of the last, partly
+    // filled slice of every row (2500 = 9 x 256 + 196 points) instead of all slices of the last rows
     const int q = b - nfc;
-    gq_pen_grid_body<true, GQ_PG_ECAP, GQ_PG_ICAP, PPT>(p, q % gx, q / gx, gq_lds);
+    gq_pen_grid_body<true, GQ_PG_ECAP, GQ_PG_ICAP, PPT>(p, q / p.B, q % p.B, gq_lds);
   }
 }
 

@@ -76,12 +76,18 @@ struct GqPenArgs {
 // address: span[2*s] = min start, span[2*s+1] = max end of the blocks with (linear block id % 64) == s
 // -DGQ_BLOCK_TIMES (development builds only, tools/block_timeline.py): the span buffer is followed by eight words per
 // block -- start, end, end of scan / ranking / finish, entries | items << 32 -- so the caller passes 128 + 8 * blocks words
+#ifdef GQ_BLOCK_TIMES
+__device__ __forceinline__ uint64_t gq_hw_id() {  // HW_ID (wave / SIMD / CU / SH / SE of gfx9) | XCC_ID << 32
+  return (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+}
+#endif
 __device__ __forceinline__ void gq_span_open(uint64_t* span, unsigned block_id) {
   const unsigned s = block_id & 63u;
   const unsigned long long t = (unsigned long long)__builtin_amdgcn_s_memrealtime();
   atomicMin((unsigned long long*)&span[2 * s], t);
 #ifdef GQ_BLOCK_TIMES
   span[128 + 8 * (size_t)block_id] = t;
+  span[128 + 8 * (size_t)block_id + 6] = gq_hw_id();
 #endif
 }
 __device__ __forceinline__ void gq_span_close(uint64_t* span, unsigned block_id) {

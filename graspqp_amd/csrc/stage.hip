@@ -32,12 +32,22 @@ __global__ __launch_bounds__(256, NC == 1 ? 4 : 2) void gq_stage_a_kernel(GqFcSt
     // the fc rows are the critical path of this launch (one long dependent instruction stream per wavefront); the query
     // wavefronts that share their SIMDs mostly wait for memory -- let the arbiter prefer the fc wavefront when both are ready
     __builtin_amdgcn_s_setprio(3);
+#ifdef GQ_BLOCK_TIMES  // where the fc rows run: one record per fc block behind those of the query blocks
+    if (threadIdx.x == 0 && p.span) {
+      uint64_t* rec = p.span + 128 + 8 * (size_t)(gridDim.x - nfc + b);
+      rec[0] = __builtin_amdgcn_s_memrealtime();
+      rec[6] = gq_hw_id();
+    }
+#endif
     float hr, hm;
     gq_fc_head_body<NC>(f, row, reinterpret_cast<float*>(gq_lds) + wv * f.n * 6, &hr, &hm);
     if (STOP) {  // large batches: the stop rule as epilogue of the last head block (no stop launch)
       const int nrow = f.B - b * GQ_HEAD_ROWS < GQ_HEAD_ROWS ? f.B - b * GQ_HEAD_ROWS : GQ_HEAD_ROWS;
       gq_fc_head_epilogue(f, b, wv, nrow, hr, hm, reinterpret_cast<unsigned*>(gq_lds) + GQ_HEAD_ROWS * f.n * 6);
     }
+#ifdef GQ_BLOCK_TIMES
+    if (threadIdx.x == 0 && p.span) p.span[128 + 8 * (size_t)(gridDim.x - nfc + b) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
   } else if (gx == 0) {  // link-driven query: one block per row (gqPenStepDesc.grid)
     gq_pen_cells_body(p, b - nfc, gq_lds);
   } else {

@@ -313,3 +313,32 @@ def test_oracle_annealing_dexgraspnet_matches_reference_optimizer(golden_dir):
         hp, idx, grad = T(f"{p}_hand_pose").to(dt), T(f"{p}_contact_idx"), T(f"{p}_grad").to(dt)
         energy, ema = T(f"{p}_energy").to(dt), T(f"{p}_ema").to(dt)
         assert step.tolist() == g[f"{p}_step"].tolist()
+
+
+def test_closest_face_helper_matches_the_oracle():
+    """graspqp_amd/utils/meshes.closest_face (numpy, asset set-up: normals of re-sampled contact candidates) against the
+    oracle's closest-point search on meshes of every kind the hands have (closed, several shells, slivers)."""
+    from graspqp_amd.utils import meshes
+    from ref_cpu import sdf as osdf
+
+    rng = np.random.default_rng(5)
+    cases = [meshes.icosphere(2, 0.05), meshes.box((0.02, 0.03, 0.01)), meshes.superquadric(4, 24, 12)]
+    sh = get_hand_spec("shadow_hand")
+    cases += [sh.link_faces(4), sh.link_faces(16)]  # a distal link and the thumb link whose mesh is several shells
+    for fv in cases:
+        fv = np.asarray(fv, dtype=np.float64)
+        lo, hi = fv.reshape(-1, 3).min(0), fv.reshape(-1, 3).max(0)
+        pts = lo + (hi - lo) * (rng.random((300, 3)) * 1.6 - 0.3)  # inside, on and around the mesh
+        q, d2, fi = meshes.closest_face(pts, fv)
+        d2o, _, _, closest = osdf.compute_sdf(torch.tensor(pts), torch.tensor(fv))
+        np.testing.assert_allclose(d2, d2o.numpy(), rtol=1e-9, atol=1e-15)
+        # the closest POINT may differ where two faces tie; its distance may not
+        np.testing.assert_allclose(((pts - q) ** 2).sum(1), d2, rtol=1e-9, atol=1e-15)
+        tie_free = np.abs(q - closest.numpy()).max(1) < 1e-9
+        assert tie_free.mean() > 0.95
+        # the reported face really contains the closest point: it lies in the face's plane and inside its edges
+        a, b, c = fv[fi, 0], fv[fi, 1], fv[fi, 2]
+        n = np.cross(b - a, c - a)
+        nn = np.linalg.norm(n, axis=1)
+        ok = nn > 1e-14
+        assert np.abs(((q - a) * n).sum(1)[ok] / nn[ok]).max() < 1e-9

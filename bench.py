@@ -32,7 +32,7 @@ import torch
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 FLOP_PER_TRI_TEST = 70.0      # one point-triangle test ~ 60-80 flop (gq_tri_rank: 45 VALU ops)
-PROFILE_TAG = "r02"           # profiles/<tag>_* files written by tools/profile_round.sh from this same command
+PROFILE_TAG = "r03"           # profiles/<tag>_* files written by tools/profile_round.sh from this same command
 
 
 def parse_args(argv=None):
@@ -45,7 +45,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--n_contact", type=int, default=12)
     ap.add_argument("--n_cone_vecs", type=int, default=4, help="friction-cone edges per contact (BASELINE configs[4] uses 8)")
-    ap.add_argument("--n_objects", type=int, default=1, help="objects per rank")
+    ap.add_argument("--n_objects", type=int, default=1, help="objects per rank.  Default 1 = BASELINE configs[1] per GPU at "
+                    "every N (weak scaling of the N=1 workload, what the SCALE runs compare); BASELINE configs[3] -- 64 meshes "
+                    "sharded over 8 GPUs, 2048 rows per rank -- is `--gpus 8 --n_objects 8`, configs[4] per hand `--gpus 8 "
+                    "--n_objects 32 --batch_size 1024 --n_cone_vecs 8 [--hand robotiq3]`")
     ap.add_argument("--hand", default="allegro")
     ap.add_argument("--fork", type=int, default=-1, help="1: every role its own launch, the two branches of the evaluation as "
                     "parallel hipGraph branches; -1 (default): follow the batch size (from 384 rows on)")
@@ -71,6 +74,11 @@ def parse_args(argv=None):
                     "more independent loads in flight than one block per row)")
     ap.add_argument("--sdf_plain_mapping", type=int, default=0, help="1: plain block->query mapping of the object SDF (A/B of the "
                     "XCD-aware placement used with >= 8 meshes)")
+    ap.add_argument("--energy_type", default="graspqp", choices=("graspqp", "dexgrasp", "tdg"),
+                    help="force-closure energy of scripts/fit.py:343-347 (graspqp = BASELINE's metric; the others: A/B lines)")
+    ap.add_argument("--plugin_surface", type=int, default=-1, help="1: after the timed region, time the reference's plugin "
+                    "surface on the same workload (compute_sdf at the reference's shapes, QPFunction / SQPLsqSolver.solve, a "
+                    "fit.py-shaped loop on the class surface); -1 (default): at N=1 on BASELINE configs[1] only")
     ap.add_argument("--selftest_ranks", action="store_true",
                     help="launcher / rendezvous / collective sequence only (no GPU work): used by the CPU test of --gpus N")
     return ap.parse_args(argv)
@@ -246,7 +254,7 @@ def rank_main(args):
     hand = ops.HandHandle(spec)
     st = GraspStepper(hand, ops.MeshSet(fvs), torch.tensor(np.stack(sps)), args.batch_size, args.n_contact,
                       fc_cfg={"n_cone_vecs": args.n_cone_vecs}, seed=1 + rank, point_grid=args.point_grid,
-                      split_self_pen=bool(args.split_self_pen))
+                      split_self_pen=bool(args.split_self_pen), energy_type=args.energy_type)
     hps, idxs = zip(*[make_initial_state(spec, f, args.batch_size, args.n_contact, 1000 + o) for f, o in zip(fvs, my_objs)])
     st.reset(torch.cat(hps).cuda(), torch.cat(idxs).cuda())
 
@@ -379,6 +387,8 @@ def rank_main(args):
         total_evals = B * world * args.steps
         nf = hand.links.n_faces
         is_cfg2 = (args.hand, args.n_objects, args.batch_size, args.n_contact, args.n_cone_vecs) == ("allegro", 1, 256, 12, 4)
+        is_cfg3 = (args.hand, args.batch_size, args.n_contact, args.n_cone_vecs) == ("allegro", 256, 12, 4) and \
+            world * args.n_objects == 64 and world > 1
         roof = None
         if n_span:
             # Dominant SDF kernel = the hand-penetration query (gq_pen_grid_kernel body; in the graph it is the pen role
@@ -392,8 +402,11 @@ def rank_main(args):
             k_ms_events = float(np.mean(evs)) if evs else None
             alg = B * st.P * hand.L * 16 + nf * 36
             ach = alg / (k_ms * 1e-3) / 1e9
-            pm = _load_json(f"{PROFILE_TAG}_pmc_traffic.json") or _load_json("r01_pmc_traffic.json")
-            src = f"profiles/{PROFILE_TAG}_pmc_traffic.json" if _load_json(f"{PROFILE_TAG}_pmc_traffic.json") else "profiles/r01_pmc_traffic.json"
+            # counter bytes are NOT measured by this run (PMC passes need rocprofv3): they are static figures from the newest
+            # committed profile of the same command, labelled as such
+            tag = next((t for t in (PROFILE_TAG, "r02", "r01") if _load_json(f"{t}_pmc_traffic.json")), None)
+            pm = _load_json(f"{tag}_pmc_traffic.json") if tag else None
+            src = f"static, from profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc passes of this command at the time of that commit)"
             traffic = None
             pen_keys = [k for k in (pm or {}) if k.startswith("gq_pen_grid_kernel<true")]
             if is_cfg2 and pen_keys:
@@ -418,17 +431,24 @@ def rank_main(args):
                                "not HBM-bound",
                     "kernel": "gq_pen_grid_kernel (hand-penetration query; " + ("in the graph it runs as the pen role of gq_stage_a_kernel)"
                                                                                if small else "its own launch on the second graph branch)"),
-                    "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                    "frac_kind": "algorithmic bytes / kernel time / peak (SURVEY 8d accounting of a TorchSDF-shaped op) -- not a utilisation",
+                    "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": min(ach / HBM_PEAK_GBPS, 1.0),
+                    "frac_unclamped": ach / HBM_PEAK_GBPS,
+                    "frac_kind": "algorithmic bytes / kernel time / peak (SURVEY 8d accounting of a TorchSDF-shaped op) -- NOT a "
+                                 "utilisation: the query culls > 99 % of the (point, link) pairs and never moves those bytes "
+                                 "(clamped at 1); the physical figures are `utilisation` (this kernel) and "
+                                 "`plugin_surface.compute_sdf` (the TorchSDF-shaped call, where N*44 B really move)",
                     "traffic": traffic, "traffic_source": src if traffic else None, "algorithmic_bytes": alg,
                     "kernel_ms": k_ms, "kernel_launches_timed": n_span, "utilisation": util}
         # per-launch table: durations from the rocprofv3 kernel trace and HBM bytes from the PMC passes of THIS command
         # (tools/profile_round.sh writes profiles/<tag>_launches.json); live numbers: launch_groups_ms above
-        launches = _load_json(f"{PROFILE_TAG}_launches.json") if is_cfg2 else None
+        ltag = next((t for t in (PROFILE_TAG, "r02") if _load_json(f"{t}_launches.json")), PROFILE_TAG)
+        launches = _load_json(f"{ltag}_launches.json") if is_cfg2 and args.energy_type == "graspqp" else None
+        if launches:
+            launches["source"] = f"static, from profiles/{ltag}_launches.json"
         # executed instructions per wavefront and VALU issue-slot utilisation of every kernel (SQ counters of the same
         # command, tools/pmc_instr.sh): the "how far from the machine's limit" figure of kernels that are neither HBM- nor
         # MFMA-bound
-        instr = _load_json(f"{PROFILE_TAG}_cfg2_instr.json") if is_cfg2 else None
+        instr = _load_json(f"{ltag}_cfg2_instr.json") if is_cfg2 else None
         if launches and instr:
             for k in launches.get("kernels", []):
                 rec = instr.get("kernels", {}).get(k["name"])
@@ -448,7 +468,12 @@ def rank_main(args):
             "config": {"workload": f"{args.hand}, {args.n_objects} YCB-style superquadric mesh(es) per GPU "
                                    f"({fvs[0].shape[0]} faces), batch_size={args.batch_size} each, n_contact={args.n_contact}, "
                                    f"2500 surface points, {args.n_cone_vecs}-edge friction cones"
-                                   + (" (BASELINE configs[1])" if is_cfg2 else ""),
+                                   + (f", energy_type={args.energy_type}" if args.energy_type != "graspqp" else "")
+                                   + (" (BASELINE configs[1])" if is_cfg2 and world == 1 else "")
+                                   + (f" (BASELINE configs[1] on each of {world} GPUs: weak scaling of the N=1 workload)"
+                                      if is_cfg2 and world > 1 else "")
+                                   + (f" (BASELINE configs[3]: {world * args.n_objects} meshes sharded over {world} GPUs)"
+                                      if is_cfg3 else ""),
                        "rows_per_gpu": B, "hip_graph": bool(args.graph), "iterations_per_graph": g_iters,
                        "eager_iterations_in_timed_region": 0,
                        "branches": getattr(st, "graph_mode", "eager") if args.graph else "eager"},
@@ -467,6 +492,20 @@ def rank_main(args):
             res["cpu_baseline_config0"] = cpu_baseline(get_hand_spec("allegro"), sph,
                                                        meshes.surface_points(sph, 2500, oversample=4, seed=42), 4, 4,
                                                        args.cpu_reps, "BASELINE configs[0] (Allegro, sphere, batch 4, n_contact 4)")
+        want_plugin = args.plugin_surface == 1 or (args.plugin_surface < 0 and world == 1 and is_cfg2 and args.energy_type == "graspqp")
+        if want_plugin:
+            # the reference's plugin surface on the same workload (what an unchanged scripts/fit.py calls), after the timed
+            # region; tools/plugin_surface.py documents the shapes
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import plugin_surface
+
+                hp0, ix0 = make_initial_state(spec, fvs[0], args.batch_size, args.n_contact, 1000 + my_objs[0])
+                res["plugin_surface"] = plugin_surface.measure(spec, fvs[0], sps[0], args.batch_size, args.n_contact, hp0, ix0,
+                                                               loop_iters=60, reps=7)
+                res["plugin_surface"]["stepper_evals_per_s"] = res["value"]
+            except Exception as e:  # diagnostics must never cost the bench line
+                res["plugin_surface"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -2,7 +2,7 @@
 # Build libgraspqp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${GQ_OUT_DIR:-$HERE/../lib}"  # GQ_OUT_DIR + GQ_EXTRA_FLAGS: variant builds for A/B runs (GRASPQP_HIP_LIB picks one)
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"

@@ -67,11 +67,31 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
   }
   const float* hp = g.hand_pose + (size_t)row * g.D;
   int64_t my_idx = 0;
+#ifdef GQ_FK_PREFETCH_BOTH
+  bool have_tables = false;
+  int clS = 0;
+  gq3 cpS = gq_mk(0, 0, 0), cnS = gq_mk(0, 0, 0);
+#endif
   const bool z_here = !sCP || (int)blockDim.x < 2 * GQ_WAVE;  // otherwise wavefront 1 computes the z-score while it waits
   if (g.has_propose) {  // the proposal of this row, then its forward kinematics: pose and indices are handed over in
     // LDS / registers, no wait for its own stores.  All operands of the proposal are requested BEFORE the barrier behind
     // which the column means become available (one memory round trip less on the row's critical path).
     const GqProposePre pp = gq_propose_prefetch(g.pr, row, lane, slot_now);
+#ifdef GQ_FK_PREFETCH_BOTH
+    // Diagnostic variant (round-2 miscompare): candidate tables of BOTH possible contacts (drawn / current
+    // index) requested before barrier A, selected after the proposal.
+    int clN = 0, clO = 0;
+    gq3 cpN = gq_mk(0, 0, 0), cnN = gq_mk(0, 0, 0), cpO = gq_mk(0, 0, 0), cnO = gq_mk(0, 0, 0);
+    if (lane < g.n) {
+      const int a = (int)pp.nix, b = (int)pp.oix;
+      clN = h.cand_link[a];
+      cpN = gq_mk(h.cand_pos[a * 3], h.cand_pos[a * 3 + 1], h.cand_pos[a * 3 + 2]);
+      cnN = gq_mk(h.cand_nrm[a * 3], h.cand_nrm[a * 3 + 1], h.cand_nrm[a * 3 + 2]);
+      clO = h.cand_link[b];
+      cpO = gq_mk(h.cand_pos[b * 3], h.cand_pos[b * 3 + 1], h.cand_pos[b * 3 + 2]);
+      cnO = gq_mk(h.cand_nrm[b * 3], h.cand_nrm[b * 3 + 1], h.cand_nrm[b * 3 + 2]);
+    }
+#endif
     float g2v[2];
     if (sPart) {  // block barrier A: the query wavefronts have left their partial column sums
       __syncthreads();
@@ -83,6 +103,15 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
       g2v[1] = lane + GQ_WAVE < g.pr.D ? g.pr.g2[lane + GQ_WAVE] : 0.0f;
     }
     gq_propose_finish(g.pr, pp, row, lane, g2v, sPose, &my_idx, z_here);
+#ifdef GQ_FK_PREFETCH_BOTH
+    {
+      const bool sw = pp.us < g.pr.switch_p;  // the rule of gq_propose_finish
+      have_tables = true;
+      clS = sw ? clN : clO;
+      cpS = sw ? cpN : cpO;
+      cnS = sw ? cnN : cnO;
+    }
+#endif
     gq_wave_sync();
     hp = sPose;
     if (g.n > GQ_WAVE) __threadfence_block();  // contacts beyond the first 64 re-read their indices from memory
@@ -92,6 +121,13 @@ __device__ __forceinline__ void gq_fk_forward_row(const GqFkArgs& g, int row, in
   // contact candidates of the (just proposed) indices: in flight while the tree is walked
   int cl0 = 0;
   gq3 cp0 = gq_mk(0, 0, 0), cn0 = gq_mk(0, 0, 0);
+#ifdef GQ_FK_PREFETCH_BOTH
+  if (have_tables) {
+    cl0 = clS;
+    cp0 = cpS;
+    cn0 = cnS;
+  } else
+#endif
   if (lane < g.n) {
     const int ci = (int)my_idx;
     cl0 = h.cand_link[ci];

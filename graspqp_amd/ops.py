@@ -173,14 +173,45 @@ def _sdf_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
 torch.library.register_autograd("graspqp_amd::compute_sdf", _sdf_bwd, setup_context=_sdf_setup)
 
 
+# Per-mesh set-up of the drop-in.  The reference hands the SAME face_verts tensor to every call (hand_model.py:351-353 keeps
+# one per link, object_model.py:146-148 one per object), so the acceleration data of a mesh -- Morton-sorted face records
+# + oriented 64-face cluster boxes (gq_meshset_create) -- is built on the first call with a tensor and kept while that
+# tensor is alive and unmodified (weak reference + data pointer + version counter; a dead tensor drops its entry).
+_MESH_CACHE = {}              # id(face_verts) -> (weakref, data_ptr, _version, MeshSet)
+_MESH_CACHE_MIN_FACES = 1024  # smaller meshes: the face loop of gq_sdf_forward is already the fastest form
+_MESH_CACHE_MAX_BRUTE_N = 65536
+
+
+def _cached_meshset(face_verts):
+    key = id(face_verts)
+    ent = _MESH_CACHE.get(key)
+    if ent is not None and ent[0]() is face_verts and ent[1] == face_verts.data_ptr() and ent[2] == face_verts._version:
+        return ent[3]
+    fv = face_verts.detach()
+    ms = MeshSet([fv.to(torch.float32).cpu().numpy()])  # one device->host copy, once per mesh
+    ref = weakref.ref(face_verts, lambda _r, k=key: _MESH_CACHE.pop(k, None))
+    _MESH_CACHE[key] = (ref, face_verts.data_ptr(), face_verts._version, ms)
+    return ms
+
+
 def compute_sdf(points: torch.Tensor, face_verts: torch.Tensor):
-    """torchsdf.compute_sdf drop-in -> (dist_sq, sign int32, normal, closest)."""
+    """torchsdf.compute_sdf drop-in -> (dist_sq, sign int32, normal, closest).
+
+    Two device paths behind the one signature: the cluster best-first search (one wavefront per query) on the cached
+    acceleration data of ``face_verts`` for meshes of >= 1024 faces unless the query count is so large and the mesh so
+    small that the per-lane face loop wins; the face loop of gq_sdf_forward otherwise (its only set-up is one face-record
+    launch per call)."""
     if points.dim() != 2 or points.shape[1] != 3:
         raise ValueError(f"compute_sdf: points must be (N,3), got {tuple(points.shape)}")
     if face_verts.dim() != 3 or tuple(face_verts.shape[1:]) != (3, 3):
         raise ValueError(f"compute_sdf: face_verts must be (F,3,3), got {tuple(face_verts.shape)}")
     if not points.is_cuda:
         raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
+    N, F = points.shape[0], face_verts.shape[0]
+    # per query: ~64k lane-instruction slots for the wavefront search against 45 F for the face loop, which however needs
+    # N / 64 >> 1024 wavefronts to fill the chip
+    if N > 0 and F >= _MESH_CACHE_MIN_FACES and not face_verts.requires_grad and (N < _MESH_CACHE_MAX_BRUTE_N or F > 1400):
+        return torch.ops.graspqp_amd.sdf_meshset(points, _cached_meshset(face_verts).hid, N)
     return torch.ops.graspqp_amd.compute_sdf(points, face_verts)
 
 

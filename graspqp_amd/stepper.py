@@ -101,6 +101,7 @@ class GraspStepper:
             self.pen_ws = torch.zeros(self.pen_nb, dtype=torch.uint8, device=self.dev)
         self._graph, self._graph_iters, self._graph_pending = None, 1, 0
         self._after_reset = False
+        self._reinit = None  # 0-dim device flag of the last step_reset: did its mask select any row (fit.py:412)
         self.kernel_events = None
         self._span = torch.zeros(64, 2, dtype=torch.int64, device=self.dev)
         self._span[:, 0] = -1  # {~0, 0}: armed
@@ -415,7 +416,9 @@ class GraspStepper:
         self._propose(st)
         self._evaluate(self.pose_new, self.idx_new, st)
         self._accept(st)
-        rej = (self.accept == 0).unsqueeze(1)
+        # ``_reinit`` (0-dim bool, device): whether the reset iteration re-initialised any row at all -- after an empty mask
+        # no leaf pose was created (fit.py:412) and this is an ordinary iteration
+        rej = ((self.accept == 0) & self._reinit).unsqueeze(1)
         self.grad.add_(torch.where(rej, self.grad_new, torch.zeros_like(self.grad_new)))
         self._slot_ctr += 1
         self._after_reset = False
@@ -428,7 +431,9 @@ class GraspStepper:
         unconditionally.  ``reset_mask=None`` takes the reference's rule z_score > ``z_threshold`` (fit.py:409) from the
         z-scores the proposal kernel has just computed -- on the device, without a host round trip.  Launched eagerly with
         the stand-alone propose / accept kernels (this happens every few hundred iterations); the device-side draw-slot
-        counter is advanced by hand so that graph replays stay in step."""
+        counter is advanced by hand so that graph replays stay in step.  A mask that selects no row (possible when
+        batch_size_each is small: the largest z-score of b rows is (b-1)/sqrt(b)) makes this an ordinary iteration, as in
+        the reference (fit.py:412); pinned by steps R_s4 / R_s5 of tests/golden/mala_ext_*.npz."""
         self.flush()
         self.draw(draws)
         st = _C.stream_ptr()
@@ -439,7 +444,11 @@ class GraspStepper:
             m = reset_mask.to(self.dev, torch.bool)
         self.reset_mask = m
         mc = m.unsqueeze(1)
-        idx_all = new_idx.to(self.dev).contiguous()
+        # fit.py:412 ``if reset_mask.sum() > 0``: with an EMPTY mask nothing is re-initialised and the iteration is an ordinary
+        # one (the masked merges below are no-ops then; the evaluation must use the proposal's indices and the next
+        # iteration must not see a leaf pose).  Kept on the device as a 0-dim flag: no host round trip.
+        self._reinit = m.any()
+        idx_all = torch.where(self._reinit, new_idx.to(self.dev), self.idx_new).contiguous()
         # masked merges with torch.where: boolean-mask indexing would synchronise with the host
         self.pose_new.copy_(torch.where(mc, new_pose.to(self.dev, torch.float32), self.pose_new))
         self.idx_new.copy_(torch.where(mc, idx_all, self.idx_new))
@@ -453,6 +462,7 @@ class GraspStepper:
         # reference quirk (hand_model.py:815-831): set_parameters(..., env_mask) gathers the contact points of ALL rows with
         # the freshly drawn indices it is handed (initializations.py:190-193), while the rows outside the mask keep
         # their proposal's indices as state -- so this iteration's energies are evaluated at ``new_idx`` everywhere
+        # (``idx_all`` is the proposal's ``idx_new`` when the mask is empty, see above)
         self._evaluate(self.pose_new, idx_all, st)
         rm = m.to(torch.uint8).contiguous() if mala else None  # AnnealingDexGraspNet.accept_step ignores reset_mask
         B, D, n, mc = self.B, self.D, self.n, self.mala

@@ -150,9 +150,11 @@ def _replay(g, run, hand, obj, be, clip):
         np.testing.assert_allclose(ss.numpy(), g[f"{p}_step_size"], rtol=1e-6)
         z = mala.z_score(energy, be)
         np.testing.assert_allclose(z.numpy(), g[f"{p}_z"], rtol=1e-5, atol=1e-7)
-        rm = None
+        rm, reinit = None, False
         if f"{p}_reset_mask" in g.files:  # fit.py:408-422 + optimizer.py:275-287
             rm = T(f"{p}_reset_mask")
+            reinit = bool(rm.any())  # fit.py:412: an empty mask re-initialises nothing (accept_step still receives it)
+        if reinit:
             hp2 = torch.where(rm[:, None], T(f"{p}_reset_pose").to(dt), hp2)
             idx2 = torch.where(rm[:, None], T(f"{p}_reset_idx"), idx2)
             step = torch.where(rm, torch.zeros_like(step), step)
@@ -166,7 +168,7 @@ def _replay(g, run, hand, obj, be, clip):
         # reference quirk (hand_model.py:815-831): with env_mask the contact points of ALL rows are gathered with the
         # indices passed in (initialize_convex_hull draws fresh ones for the whole batch, initializations.py:190-193),
         # while the stored contact_point_indices of the other rows stay the proposal's
-        hand.set_parameters(hpr, idx2 if rm is None else T(f"{p}_reset_idx"))
+        hand.set_parameters(hpr, T(f"{p}_reset_idx") if reinit else idx2)
         new_e = ref_cpu.total_energy(ref_cpu.calculate_energy(hand, obj))
         new_e.sum().backward()
         g2 = hand.hand_pose.grad.detach()
@@ -179,7 +181,7 @@ def _replay(g, run, hand, obj, be, clip):
         # MalaStar keeps as old_grad_hand_pose (optimizer.py:266) -- so rejected rows get old + new gradient back.  (A
         # non-leaf pose with retain_grad, the normal case, accumulates out of place and leaves the kept tensor alone.)
         grad_old = grad + g2 if after_reset else grad
-        after_reset = rm is not None
+        after_reset = reinit
         hp, idx, grad = mala.merge(acc, hp2, hp), mala.merge(acc, idx2, idx), mala.merge(acc, g2, grad_old)
         energy = mala.merge(acc, new_e.detach(), energy)
         np.testing.assert_allclose(hp.numpy(), g[f"{p}_hand_pose"], rtol=1e-6, atol=1e-7)
@@ -198,6 +200,10 @@ def test_oracle_mala_reset_and_decay_match_reference_optimizer(golden_dir):
     assert float(g["R_s1_step_size"][0]) == pytest.approx(0.005 * 0.95**2, rel=1e-6)
     assert float(g["R_s3_step_size"][int(np.argmin(g["R_s2_reset_mask"]))]) == pytest.approx(0.005 * 0.95**3, rel=1e-6)
     assert g["R_s2_accept"][g["R_s2_reset_mask"]].all() and 0 < g["R_s2_reset_mask"].sum() < len(g["R_s2_accept"])
+    # iteration 4: a scheduled re-initialisation with an EMPTY mask (fit.py:412), iteration 5 the one after it -- both are
+    # ordinary iterations, and both contain rejected rows (whose restored gradient would show an old + new accumulation)
+    assert int(g["R_n_steps"]) == 5 and not g["R_s4_reset_mask"].any()
+    assert (~g["R_s4_accept"]).any() and (~g["R_s5_accept"]).any()
     _replay(g, "R", hand, obj, be, clip=False)
 
 

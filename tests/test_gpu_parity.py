@@ -97,6 +97,48 @@ def test_sdf_points_kernel_and_analytic_sphere(gq):
     assert torch.equal(d2b.cpu(), d2[:5000].cpu())
 
 
+def test_compute_sdf_mesh_cache_follows_the_face_verts_tensor(gq):
+    """compute_sdf keeps the acceleration data of a mesh (>= 1024 faces) while the caller's face_verts tensor is alive and
+    unmodified: a second call reuses it, an in-place change of the tensor rebuilds it, a dead tensor drops its entry; the
+    cached route (cluster search) and the uncached one (face loop) return the same distances."""
+    import gc
+
+    rng = np.random.default_rng(4)
+    fv_np = meshes.superquadric(5, 48, 24)
+    assert fv_np.shape[0] >= 1024
+    fv = torch.tensor(fv_np, device="cuda")
+    pts_np = (rng.normal(size=(4096, 3)) * 0.08).astype(np.float32)
+    pts = torch.tensor(pts_np, device="cuda")
+    n0 = len(gq.ops._MESH_CACHE)
+    d2a, sga, _, cla = gq.ops.compute_sdf(pts, fv)
+    assert len(gq.ops._MESH_CACHE) == n0 + 1
+    ms = gq.ops._MESH_CACHE[id(fv)][3]
+    d2b, _, _, _ = gq.ops.compute_sdf(pts, fv)
+    assert gq.ops._MESH_CACHE[id(fv)][3] is ms and torch.equal(d2a, d2b)
+    # the uncached face loop (registered op on the raw tensors) agrees on the distance bit for bit
+    d2c, sgc, _, _ = torch.ops.graspqp_amd.compute_sdf(pts, fv)
+    # (both rank the faces with gq_tri_rank and finish the winner exactly; faces that tie within the ranking noise of
+    # ~1e-10 m^2 may swap, which moves a distance by a few ulp at most)
+    assert (d2a == d2c).float().mean() > 0.999 and (sga == sgc).float().mean() > 0.999
+    np.testing.assert_allclose(d2a.cpu().numpy(), d2c.cpu().numpy(), rtol=1e-5, atol=1e-10)
+    od2, _, _, _ = osdf.compute_sdf(torch.tensor(pts_np[:512], dtype=torch.float64), torch.tensor(fv_np, dtype=torch.float64))
+    np.testing.assert_allclose(np.sqrt(d2a[:512].cpu().numpy()), np.sqrt(od2.numpy()), rtol=1e-4, atol=2e-7)
+    # in-place change of the mesh: rebuilt, and the result follows the new mesh
+    fv.mul_(0.5)
+    d2s, _, _, _ = gq.ops.compute_sdf(pts, fv)
+    assert gq.ops._MESH_CACHE[id(fv)][3] is not ms
+    od2s, _, _, _ = osdf.compute_sdf(torch.tensor(pts_np[:512], dtype=torch.float64), torch.tensor(fv_np, dtype=torch.float64) * 0.5)
+    np.testing.assert_allclose(np.sqrt(d2s[:512].cpu().numpy()), np.sqrt(od2s.numpy()), rtol=1e-4, atol=2e-7)
+    # gradient route unchanged (only dist_sq w.r.t. points)
+    pg = pts.clone().requires_grad_()
+    d2g, _, _, clg = gq.ops.compute_sdf(pg, fv)
+    d2g.sum().backward()
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), 2 * (pts - clg).cpu().numpy(), rtol=1e-5, atol=1e-7)
+    del fv, ms
+    gc.collect()
+    assert len(gq.ops._MESH_CACHE) == n0
+
+
 def test_sdf_backward_and_edge_cases(gq):
     fv = torch.tensor(meshes.box(), device="cuda")
     p = torch.randn(257, 3, device="cuda").mul(0.06).requires_grad_()
@@ -721,6 +763,29 @@ def test_mala_reset_iteration_and_decays_match_reference_optimizer(gq, golden_di
     assert rejected, "the fixture must contain a rejected row after the reset"
     _check_iteration(st, g, "R_s3", check_grad_rows=rejected)
     assert not st._after_reset
+    # a scheduled re-initialisation whose mask comes out EMPTY (fit.py:412: nothing is re-initialised) and the iteration
+    # after it: both are ordinary iterations -- evaluated at the proposal's contact indices, no unconditional accepts, and
+    # the rows rejected in R_s5 get the OLD gradient back (no old + new accumulation: no leaf pose was created).  Once
+    # with the mask passed in, once with the on-device rule z > threshold (fit.py:409).
+    for how in ("mask", "z_rule"):
+        _force_state(st, g, "R_s3", f32)
+        m4 = torch.tensor(g["R_s4_reset_mask"])
+        assert not m4.any()
+        if how == "mask":
+            st.step_reset(m4, f32("R_s4_reset_pose"), torch.tensor(g["R_s4_reset_idx"]), draws=draws("R_s4"))
+        else:
+            st.step_reset(None, f32("R_s4_reset_pose"), torch.tensor(g["R_s4_reset_idx"]), draws=draws("R_s4"),
+                          z_threshold=float(g["R_empty_mask_threshold"]))
+        torch.cuda.synchronize()
+        assert not bool(st.reset_mask.any())
+        _check_iteration(st, g, "R_s4", check_grad_rows=[r for r, a in enumerate(g["R_s4_accept"].tolist()) if not a])
+        _force_state(st, g, "R_s4", f32)
+        st.step(draws=draws("R_s5"))
+        torch.cuda.synchronize()
+        rejected = [r for r, a in enumerate(g["R_s5_accept"].tolist()) if not a]
+        assert rejected
+        _check_iteration(st, g, "R_s5", check_grad_rows=rejected)
+        np.testing.assert_allclose(st.grad.cpu().numpy()[rejected], g["R_s4_grad"][rejected], rtol=1e-6, atol=1e-9)
 
 
 def test_mala_clip_grad_with_nan_inf_matches_reference_optimizer(gq, golden_dir):

@@ -317,10 +317,11 @@ def _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, o
     reset_mask = None
     if reset is not None:
         reset_mask, new_pose, new_cidx = reset
-        hp = new_pose.clone()
-        hp.requires_grad_()
-        hand.set_parameters(hp, new_cidx, env_mask=reset_mask)  # initializations.py:193
-        opt.reset_envs(reset_mask)  # fit.py:422
+        if reset_mask.sum() > 0:  # fit.py:412 -- an all-false mask re-initialises nothing: an ordinary iteration, but
+            hp = new_pose.clone()  # accept_step still receives the (all-false) mask (fit.py:447-453)
+            hp.requires_grad_()
+            hand.set_parameters(hp, new_cidx, env_mask=reset_mask)  # initializations.py:193
+            opt.reset_envs(reset_mask)  # fit.py:422
         out.update({f"{tag}_reset_mask": reset_mask.clone(), f"{tag}_reset_pose": new_pose.clone(),
                     f"{tag}_reset_idx": new_cidx.clone()})
     opt.zero_grad()
@@ -392,7 +393,18 @@ def gen_mala_ext(ref_energy, ref_opt):
             _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s2",
                            reset=(reset_mask, hp_new, idx_new))
             _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s3")
-            out["R_n_steps"] = 3
+            # a scheduled re-initialisation whose mask comes out EMPTY (fit.py:408-412: no row has z > threshold -- the
+            # threshold is put above the largest z-score a batch of `be` rows can reach, (be - 1) / sqrt(be)), followed by
+            # one more ordinary iteration: neither may differ from an unscheduled iteration
+            eb = energy.view(-1, be)
+            z = ((eb - eb.mean(-1).unsqueeze(-1)) / eb.std(-1).unsqueeze(-1)).view(-1)
+            empty = z > 1.6
+            assert int(empty.sum()) == 0
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s4",
+                           reset=(empty, hp_new, idx_new))
+            _fit_iteration(ref_energy, opt, hand, obj, fc, names, w, energy, be, B, n, out, "R_s5")
+            out["R_n_steps"] = 5
+            out["R_empty_mask_threshold"] = 1.6
         else:
             # the first gradient is NOT zeroed here: the clip path needs a non-trivial gradient around the bad entries
             bad = hand.hand_pose.grad.detach().clone()
@@ -406,7 +418,7 @@ def gen_mala_ext(ref_energy, ref_opt):
                 out[f"obj{i}_face_verts"] = fvs[i]
                 out[f"obj{i}_surface_points"] = sps[i]
     np.savez_compressed(os.path.join(OUT, "mala_ext_allegro_sphere_b8_n4.npz"), **to_np(out))
-    print("mala_ext: R accepts", [out[f"R_s{i}_accept"].tolist() for i in (1, 2, 3)], "reset", out["R_s2_reset_mask"].tolist())
+    print("mala_ext: R accepts", [out[f"R_s{i}_accept"].tolist() for i in (1, 2, 3, 4, 5)], "reset", out["R_s2_reset_mask"].tolist())
     print("mala_ext: C accepts", [out[f"C_s{i}_accept"].tolist() for i in (1, 2)])
 
 

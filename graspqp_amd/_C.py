@@ -98,6 +98,11 @@ PenStepDesc = _struct("PenStepDesc", [
     ("pose_dim", "i"), ("Rg", "p"), ("link_T", "p"), ("dis", "p"), ("link", "p"), ("gvec", "p"), ("link_wrench", "p"),
     ("gRt", "p"), ("w_pen", "f"), ("e_pen", "p"), ("span", "p"), ("span_acc", "p"), ("hand", "p"), ("w_spen", "f"),
     ("e_spen", "p"), ("g_sphere_centers", "p"), ("sphere_centers", "p"), ("grid", "p"), ("patch_spheres", "p")])
+AltFcDesc = _struct("AltFcDesc", [
+    ("dist_sq", "p"), ("sign", "p"), ("obj_dir", "p"), ("closest", "p"), ("contact_pts", "p"), ("hand_normals", "p"),
+    ("cog", "p"), ("batch", "l"), ("n_contact", "i"), ("energy", "i"), ("torque_weight", "f"), ("directions", "p"),
+    ("n_directions", "i"), ("friction", "f"), ("obb_length", "f"), ("enable_density", "i"), ("scale", "f"), ("w_dis", "f"),
+    ("w_fc", "f"), ("obj_normal", "p"), ("g_contact_pts", "p"), ("g_hand_normals", "p"), ("e_fc", "p")])
 
 ProposeDesc = _struct("ProposeDesc", [
     ("hand_pose", "p"), ("grad", "p"), ("contact_idx", "p"), ("u_switch", "p"), ("new_idx", "p"), ("ema", "p"),

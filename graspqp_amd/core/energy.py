@@ -46,6 +46,13 @@ def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[],
     if "E_manipulativity" in energy_names:
         # energy.py:80-87.  Value only: the reference differentiates it through the Jacobian and the pseudo-inverse, but
         # scripts/fit.py cannot select it (no weight for it: fit.py:363-371 raises on the unknown name), so no backward here
+        if hand_model.hand_pose.requires_grad:
+            import warnings
+
+            warnings.warn("graspqp_amd: E_manipulativity is VALUE-ONLY (no gradient reaches hand_pose through it; the reference "
+                          "differentiates it through the contact Jacobian and its pseudo-inverse, core/energy.py:80-87). "
+                          "Weighting it in an energy that is back-propagated adds nothing to the gradient.", RuntimeWarning,
+                          stacklevel=2)
         E_jacobian = hand_model.get_manipulability(
             contact_normal * distance.detach().unsqueeze(-1).abs().clamp(min=5e-3), hand_model.contact_point_indices)
         losses["E_manipulativity"] = E_jacobian.mean(-1)

@@ -15,12 +15,12 @@ echo "$SIG" > "$OUT/.flags"
 deps() {  # headers each translation unit includes
   case "$1" in
     qp_lr|fcstep) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h" ;;
-    stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h kin_dev.h" ;;
+    stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h kin_dev.h metric_dev.h" ;;
     qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
     sdf) echo "common.h tri.h pen_dev.h sdf_dev.h wave.h" ;;
     fc) echo "common.h fc_dev.h wave.h" ;;
     loop) echo "common.h fc_dev.h loop_dev.h wave.h" ;;
-    metric) echo "common.h wave.h" ;;
+    metric) echo "common.h wave.h metric_dev.h" ;;
     init) echo "common.h wave.h" ;;
     export) echo "common.h kin_dev.h wave.h" ;;
     kin) echo "common.h loop_dev.h sdf_dev.h tri.h kin_dev.h wave.h" ;;

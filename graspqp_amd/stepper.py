@@ -28,8 +28,9 @@ class GraspStepper:
                  n_contact: int, weights=None, fc_cfg=None, mala_cfg=None, device="cuda", seed=1,
                  penetration_only: bool = True, energy_type: str = "graspqp", optimizer: str = "mala_star",
                  tdg_directions=None, point_grid: int = 0, split_self_pen: bool = True):
-        """energy_type: "graspqp" (default; the fused launches) | "dexgrasp" | "tdg" (scripts/fit.py:343-347; the
-        force-closure term is then one extra launch after the contact terms).  optimizer: "mala_star" | "dexgraspnet"
+        """energy_type: "graspqp" (default) | "dexgrasp" | "tdg" (scripts/fit.py:343-347); every type has the fused four-
+        launch form (the force-closure role of the first stage launch is the contact terms + that energy) and the per-role
+        form on two graph branches.  optimizer: "mala_star" | "dexgraspnet"
         (AnnealingDexGraspNet, core/optimizer.py:11-149: no z-score in the temperature, no re-initialisation)."""
         if energy_type not in ("graspqp", "dexgrasp", "tdg") or optimizer not in ("mala_star", "dexgraspnet"):
             raise NotImplementedError(f"energy_type={energy_type!r} / optimizer={optimizer!r}")
@@ -108,7 +109,7 @@ class GraspStepper:
         self._span_acc = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self._side = None
         self.penetration_only = int(penetration_only)  # E_pen only needs dis > 0 (energy.py:59-61)
-        self._can_fuse = self.penetration_only == 1 and energy_type == "graspqp"
+        self._can_fuse = self.penetration_only == 1  # every energy type has a fused form (gq_fc_pen_step / gq_alt_pen_step)
         # bounding spheres of the 256-point slices of the surface points: block-level link pre-cull of the penetration query
         self.patch = torch.empty(self.n_obj, (self.P + 255) // 256, 4, device=self.dev)
         _C.call("gq_surface_patches", _C.f32(self.surf), ctypes.c_int64(self.n_obj), ctypes.c_int64(self.P), _C.f32(self.patch),
@@ -159,6 +160,21 @@ class GraspStepper:
             pd.e_spen, pd.g_sphere_centers, pd.sphere_centers = (self.terms_new[3].data_ptr(), self.g_sph_w.data_ptr(),
                                                                   self.spheres.data_ptr())
         self._fc_desc, self._pen_desc = fd, pd
+        self._alt_desc = None
+        if energy_type != "graspqp":  # the fused launches of the other energy types (gq_alt_pen_step)
+            ad = _C.AltFcDesc()
+            ad.dist_sq, ad.sign, ad.obj_dir, ad.closest = fd.dist_sq, fd.sign, fd.obj_dir, fd.closest
+            ad.contact_pts, ad.hand_normals, ad.cog = fd.contact_pts, fd.hand_normals, fd.cog
+            ad.batch, ad.n_contact = B, n
+            ad.energy = 1 if energy_type == "dexgrasp" else 2
+            ad.torque_weight = 0.0  # the reference's call site (core/energy.py:35-42)
+            if energy_type == "tdg":
+                ad.directions, ad.n_directions = self.tdg_dirs.data_ptr(), int(self.tdg_dirs.shape[0])
+                ad.friction, ad.obb_length, ad.enable_density, ad.scale = 0.2, 0.2, 1, 100.0  # as _eval_contacts
+            ad.w_dis, ad.w_fc = float(self.w["E_dis"]), float(self.w["E_fc"])
+            ad.obj_normal, ad.g_contact_pts, ad.g_hand_normals = fd.obj_normal, fd.g_contact_pts, fd.g_hand_normals
+            ad.e_fc = self.terms_new[1].data_ptr()
+            self._alt_desc = ad
         # MalaStar.try_step / accept_step as head / tail of the FK kernels
         self._fuse_loop = True
         self._slot_ctr = torch.zeros(2, dtype=torch.int32, device=self.dev)
@@ -274,7 +290,10 @@ class GraspStepper:
                         _C.f32(self.d2), _C.i32(self.sgn), _C.f32(self.onrm), _C.f32(self.closest), st)
             # both branches side by side in two launches
             self._pen_desc.hand_pose = pose.data_ptr()
-            _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
+            if self._alt_desc is None:
+                _C.call("gq_fc_pen_step", ctypes.byref(self._fc_desc), ctypes.byref(self._pen_desc), st)
+            else:
+                _C.call("gq_alt_pen_step", ctypes.byref(self._alt_desc), ctypes.byref(self._pen_desc), st)
         elif not fork:
             self._eval_contacts(st)
             if split_spen:

@@ -153,6 +153,22 @@ typedef struct gqPenStepDesc {
   const float* patch_spheres;                   /* optional: gq_surface_patches (see gq_hand_pen_forward) */
 } gqPenStepDesc;
 int gq_fc_pen_step(const gqFcStepDesc* fc, const gqPenStepDesc* pen, void* stream);
+/* gq_fc_pen_step for the reference's other energy types (scripts/fit.py:343-347; metrics/ops/dexgrasp.py:4-34,
+ * metrics/ops/tdg.py:147-239): the contact terms of E_dis (gq_contact_terms) and gq_dexgrasp_energy / gq_tdg_energy (with
+ * upstream weight w_fc, accumulated onto w_dis dE_dis/dp) as the first role of the first launch, beside the penetration
+ * query; penetration backward (+ self penetration) in the second.  energy: 1 = dexgrasp, 2 = tdg; the remaining fields are
+ * the parameters of the same names of gq_contact_terms / gq_dexgrasp_energy / gq_tdg_energy.  Same bits as the separate
+ * launches.                                                                                                          */
+typedef struct gqAltFcDesc {
+  const float* dist_sq; const int32_t* sign; const float* obj_dir; const float* closest;
+  const float* contact_pts; const float* hand_normals; const float* cog;
+  int64_t batch; int32_t n_contact; int32_t energy;
+  float torque_weight;                                            /* dexgrasp (0 at the reference's call site) */
+  const float* directions; int32_t n_directions; float friction, obb_length; int32_t enable_density; float scale; /* tdg */
+  float w_dis, w_fc;
+  float* obj_normal; float* g_contact_pts; float* g_hand_normals; float* e_fc;
+} gqAltFcDesc;
+int gq_alt_pen_step(const gqAltFcDesc* alt, const gqPenStepDesc* pen, void* stream);
 
 /* ---- hand kinematics: HandModel.set_parameters / fk / _set_contact_idxs -----------------------------
  * reference: core/hand_model.py:762-766,787-873,1220-1267  utils/transforms.py:5-13

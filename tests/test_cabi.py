@@ -101,7 +101,7 @@ def test_descriptor_struct_layouts_match_the_header(tmp_path):
         pytest.skip("no C compiler")
     pairs = {"gqHandDesc": _C.HandDesc, "gqRowEnergyDesc": _C.RowEnergyDesc, "gqFcStepDesc": _C.FcStepDesc,
              "gqPenStepDesc": _C.PenStepDesc, "gqProposeDesc": _C.ProposeDesc, "gqAcceptDesc": _C.AcceptDesc,
-             "gqSdfDesc": _C.SdfDesc, "gqInitDesc": _C.InitDesc}
+             "gqSdfDesc": _C.SdfDesc, "gqInitDesc": _C.InitDesc, "gqAltFcDesc": _C.AltFcDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "graspqp_hip.h"', "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')

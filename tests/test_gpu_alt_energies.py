@@ -120,19 +120,23 @@ def test_stepper_with_other_energy_types(gq, energy_type):
     assert (hm.hand_pose.grad - grad).norm() <= 1e-3 * grad.norm()
     # iterations: graph replay == eager, finite
     outs = []
-    for rep in range(2):
+    for rep in range(3):
         s2 = gq.stepper.GraspStepper(hand, gq.ops.MeshSet(fvs), torch.tensor(np.stack(sps)), be, n, energy_type=energy_type,
                                      tdg_directions=dirs, seed=5)
         s2.reset(hp.float().cuda(), idx.cuda())
-        if rep == 1:
+        if rep == 1:  # the fused four-launch form (gq_alt_pen_step): contact terms + this energy beside the penetration query
             s2.capture(iters=2)
+            assert s2.graph_mode == "one grid"
+        if rep == 2:  # per-role launches on two graph branches (what batches >= 384 rows take)
+            s2.capture(fork=True, iters=2)
+            assert s2.graph_mode == "graph branches"
         for _ in range(4):
             s2.step()
         s2.flush()
         torch.cuda.synchronize()
         outs.append((s2.energy.clone(), s2.hand_pose.clone(), s2.contact_idx.clone()))
     assert torch.isfinite(outs[0][0]).all()
-    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and all(torch.equal(a, b) for a, b in zip(outs[0], outs[2]))
 
 
 def test_annealing_dexgraspnet_matches_reference_optimizer(gq, golden_dir):
@@ -198,10 +202,22 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     hm.set_parameters(hp, torch.tensor(g["contact_idx"]).cuda())
     fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
     names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints", "E_prior", "E_wall", "E_manipulativity"]
-    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+    with pytest.warns(RuntimeWarning, match="VALUE-ONLY"):  # a differentiable pose + this term: no silent zero gradient
+        losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
     np.testing.assert_allclose(losses["E_prior"].detach().cpu().numpy(), g["opt_E_prior"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(losses["E_wall"].detach().cpu().numpy(), g["opt_E_wall"], rtol=1e-5, atol=1e-6)
     assert losses["E_manipulativity"].shape == (n_obj * be,) and torch.isfinite(losses["E_manipulativity"]).all()
+    # its VALUE against the oracle's restatement of core/energy.py:80-87 (contact Jacobian J_v + J_w x r, damped
+    # pseudo-inverse with lambda = 1e-3, mean squared residual of the contact velocities that the joints cannot produce)
+    from ref_cpu import export as oexp
+
+    oh = omodels.OracleHand(spec, torch.float64)
+    oo = omodels.OracleObject([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                              [g[f"obj{i}_surface_points"] for i in range(n_obj)], be, torch.float64)
+    oh.set_parameters(torch.tensor(g["opt_hand_pose"], dtype=torch.float64), torch.tensor(g["contact_idx"]))
+    dist_o, cn_o = oo.cal_distance(oh.contact_points)
+    _, res_o = oexp.get_req_joint_velocities(oh, cn_o * dist_o.unsqueeze(-1).abs().clamp(min=5e-3), oh.contact_point_indices)
+    np.testing.assert_allclose(losses["E_manipulativity"].cpu().numpy(), res_o.mean(-1).numpy(), rtol=2e-3, atol=1e-9)
     (2.0 * losses["E_prior"] + 3.0 * losses["E_wall"]).sum().backward()
     gref = g["opt_grad"]
     assert np.linalg.norm(hm.hand_pose.grad.cpu().numpy() - gref) <= 1e-4 * np.linalg.norm(gref)

@@ -19,6 +19,7 @@ from ref_cpu import models as omodels  # noqa: E402
 from ref_cpu import qp as oqp  # noqa: E402
 from ref_cpu import span as ospan  # noqa: E402
 
+from _parity import assert_tail_within_fp32_noise, oracle_fc_fp32_noise  # noqa: E402
 from _scenes import hetero_contacts  # noqa: E402
 from graspqp_amd.hands import get_hand_spec  # noqa: E402
 from graspqp_amd.utils import meshes  # noqa: E402
@@ -47,6 +48,7 @@ def _rel(a, b, floor=1e-12):
     ("robotiq3", 12, 8, 8, 1024),     # configs[4] share: 8 meshes x 1024 = 8192 rows, 8-edge cones, nz = 96
     ("allegro", 12, 4, 3, 171),       # 513 rows: the last force-closure head block holds ONE row (stop-rule epilogue)
     ("robotiq3", 12, 8, 32, 1024),    # configs[4] per rank at its stated size: 32 meshes x 1024 = 32 768 rows
+    ("allegro", 12, 8, 32, 1024),     # ... and its Allegro half (16 joints, 14 links, 25 penetration spheres, nz = 96)
 ])
 def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     from bench import make_initial_state
@@ -90,7 +92,7 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
 
     # (b) E_fc and its contact-point gradient of the WHOLE batch against the oracle's metric (fp64) run on the same
     # B x n contact points / object normals: identical batch composition, so qpth's batch-global stop rule sees the
-    # same rows (1e-4 median / 5e-3 max, gradient 2e-2 norm-wise, n_iter equal)
+    # same rows (1e-4 median, p99 / max <= 2x the oracle's own fp32 noise on the same rows; gradient 2e-2 norm-wise, n_iter equal)
     st = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg,
                                  weights={"E_dis": 0.0, "E_fc": 1.0, "E_pen": 0.0, "E_spen": 0.0, "E_joints": 0.0})
     t_fc, _, _ = st.evaluate(pose, cidx)
@@ -100,7 +102,8 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     n_iter_o = oqp.LAST["n_iter"]
     eo.sum().backward()
     rel = _rel(t_fc["E_fc"].cpu().numpy(), eo.detach().numpy())
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert_tail_within_fp32_noise(rel, oracle_fc_fp32_noise(ospan, st.cpts.cpu(), st.obj_normal.cpu(), st.cog.cpu(), k, eo.detach()),
+                                  f"E_fc {hand_name} {B} rows")
     assert int(st.n_iter.item()) == n_iter_o, (int(st.n_iter.item()), n_iter_o)
     gfc = np.linalg.norm(st.g_cpts.cpu().numpy() - po.grad.numpy()) / np.linalg.norm(po.grad.numpy())
     assert gfc < 2e-2, gfc
@@ -267,7 +270,8 @@ def test_qp_heterogeneous_batch_deciding_row_in_last_tile(gq, n, k, B):
     assert int(nit.item()) == n_iter_o, (int(nit.item()), n_iter_o)
     val = 0.5 * ((Fg @ x.unsqueeze(-1)).squeeze(-1) ** 2).sum(-1)
     rel = _rel(2 * (val.detach().cpu().numpy() + 0.01), 2 * (val_o.numpy() + 0.01))
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    val_32, _ = oqp.lsq_box_qp(Fb.float(), b0.float(), 1.0, 21.0, box_form=True)  # the oracle's own fp32 noise on these rows
+    assert_tail_within_fp32_noise(rel, _rel(2 * (val_32.double().numpy() + 0.01), 2 * (val_o.numpy() + 0.01)), f"QP value B={B}")
     # x itself: Q = F'F + 1e-4 I has rank 6 + ridge, so rows with bunched contacts have directions along which x is
     # determined by the ridge alone (the value is flat there): nearly all entries agree tightly, a few outliers may not
     dx = np.abs(x.detach().cpu().numpy() - x_o.numpy())

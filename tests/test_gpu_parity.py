@@ -18,6 +18,7 @@ from ref_cpu import qp as oqp  # noqa: E402
 from ref_cpu import sdf as osdf  # noqa: E402
 from ref_cpu import span as ospan  # noqa: E402
 
+from _parity import assert_tail_within_fp32_noise, oracle_fc_fp32_noise, rel_err  # noqa: E402
 from graspqp_amd.hands import get_hand_spec  # noqa: E402
 from graspqp_amd.utils import meshes  # noqa: E402
 
@@ -180,7 +181,8 @@ def test_qp_iterate_matches_oracle(gq, golden_dir, n, k):
     x = gq.ops.lsq_box_qp(Fg, None, 1.0, 21.0)
     val = 0.5 * ((Fg @ x.unsqueeze(-1)).squeeze(-1) ** 2).sum(-1)
     rel = _rel(2 * (val.detach().cpu().numpy() + 0.01), 2 * (val_o.numpy() + 0.01))
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    val_32, _ = oqp.lsq_box_qp(F.float(), b0.float(), 1.0, 21.0, box_form=True)  # the oracle's own fp32 noise on these rows
+    assert_tail_within_fp32_noise(rel, _rel(2 * (val_32.double().numpy() + 0.01), 2 * (val_o.numpy() + 0.01)), f"QP value n={n} k={k}")
     assert np.abs(x.detach().cpu().numpy() - x_o.numpy()).max() < 5e-2
     assert (x.min() >= 1.0 - 1e-4) and (x.max() <= 21.0 + 1e-3)
     # gradient of the value w.r.t. F (direct + implicit KKT part)
@@ -238,7 +240,7 @@ def test_fc_energy_and_gradient(gq, golden_dir, n, k):
     e, xs = gq.ops.fc_energy(pg, nrm.float().cuda(), cog.float().cuda(), n_cone_vecs=k)
     e.sum().backward()
     rel = _rel(e.detach().cpu().numpy(), eo.detach().numpy())
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert_tail_within_fp32_noise(rel, oracle_fc_fp32_noise(ospan, pts, nrm, cog, k, eo), f"E_fc n={n} k={k}")
     ge = np.linalg.norm(pg.grad.cpu().numpy() - po.grad.numpy()) / np.linalg.norm(po.grad.numpy())
     assert ge < 2e-2, ge
     # the grasp matrix itself is pinned by the reference's own span.py (fixture F)
@@ -369,9 +371,16 @@ def test_energy_and_gradient_match_golden(gq, golden_dir, tag, n):
     torch.cuda.synchronize()
     for k in ("E_dis", "E_joints", "E_pen", "E_spen"):
         np.testing.assert_allclose(terms[k].cpu().numpy(), g[k], rtol=2e-4, atol=2e-6, err_msg=k)
-    np.testing.assert_allclose(terms["E_fc"].cpu().numpy(), g["E_fc"], rtol=5e-3, err_msg="E_fc")
+    # E_fc and the total: within 2x the error the oracle itself makes in fp32 on this very scene (fixture values are fp64)
+    n_obj, be = int(g["n_obj"]), int(g["batch_size_each"])
+    oh32 = omodels.OracleHand(get_hand_spec("allegro"), torch.float32)
+    oo32 = omodels.OracleObject([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                                [g[f"obj{i}_surface_points"] for i in range(n_obj)], be, torch.float32)
+    oh32.set_parameters(torch.tensor(g["hand_pose"], dtype=torch.float32), torch.tensor(g["contact_idx"]))
+    lo32 = ref_cpu.calculate_energy(oh32, oo32, box_form=True)
+    assert_tail_within_fp32_noise(_rel(terms["E_fc"].cpu().numpy(), g["E_fc"]), _rel(lo32["E_fc"].numpy(), g["E_fc"]), "E_fc")
     rel = _rel(total.cpu().numpy(), g["total"])
-    assert np.median(rel) < 1e-4 and rel.max() < 2e-3, rel
+    assert_tail_within_fp32_noise(rel, _rel(ref_cpu.total_energy(lo32).numpy(), g["total"]), "total energy")
     gg, go = grad.cpu().numpy(), g["grad"]
     assert np.linalg.norm(gg - go) / np.linalg.norm(go) < 5e-3
     # autograd route == fused stepper (same kernels)
@@ -550,7 +559,8 @@ def test_config2_properties_and_determinism(gq):
     # the GPU evaluated -- identical batch composition, so qpth's batch-global stop rule sees the same rows
     eo, _ = ospan.e_fc(st2.cpts.cpu().double(), st2.obj_normal.cpu().double(), st2.cog.cpu().double(), k=4, box_form=True)
     rel = _rel(t2["E_fc"].cpu().numpy(), eo.numpy())
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert_tail_within_fp32_noise(rel, oracle_fc_fp32_noise(ospan, st2.cpts.cpu(), st2.obj_normal.cpu(), st2.cog.cpu(), 4, eo),
+                                  "E_fc, 256 rows")
     # ... and its gradient w.r.t. the contact points (KKT-implicit QP backward + direct + singular-value parts), full batch
     st4 = gq.stepper.GraspStepper(hand, ms, torch.tensor(sp)[None], B, n,
                                   weights={"E_dis": 0.0, "E_fc": 1.0, "E_pen": 0.0, "E_spen": 0.0, "E_joints": 0.0})
@@ -567,7 +577,8 @@ def test_config2_properties_and_determinism(gq):
 # two QP columns per lane), several objects per process, and a batch large enough for the stand-alone stop-rule launch
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("hand_name,n,k,n_obj,be", [("shadow_hand", 16, 4, 2, 40), ("robotiq3", 12, 8, 1, 24),
-                                                    ("allegro", 12, 4, 3, 100)])
+                                                    ("allegro", 12, 4, 3, 100),
+                                                    ("allegro", 12, 8, 2, 32)])  # the Allegro half of BASELINE configs[4], small
 def test_stepper_other_configs(gq, hand_name, n, k, n_obj, be):
     from graspqp_amd.core.energy import calculate_energy
     from graspqp_amd.core.hand_model import HandModel
@@ -615,7 +626,8 @@ def test_stepper_other_configs(gq, hand_name, n, k, n_obj, be):
     # E_fc tightly: the oracle's metric on the whole batch of contact points the GPU evaluated (same stop-rule input)
     eo, _ = ospan.e_fc(st.cpts.cpu().double(), st.obj_normal.cpu().double(), st.cog.cpu().double(), k=k, box_form=True)
     rel = _rel(terms["E_fc"].cpu().numpy(), eo.numpy())
-    assert np.median(rel) < 1e-4 and rel.max() < 5e-3, (np.median(rel), rel.max())
+    assert_tail_within_fp32_noise(rel, oracle_fc_fp32_noise(ospan, st.cpts.cpu(), st.obj_normal.cpu(), st.cog.cpu(), k, eo),
+                                  f"E_fc {hand_name} n={n} k={k}")
     # (3) iterations run (graph replay == eager), stay finite and are reproducible
     outs = []
     for rep in range(2):

@@ -56,7 +56,7 @@ def oracle_fc(cpts, onrm, cog, k, dtype, box_form):
     from ref_cpu import qp as oqp
     from ref_cpu import span as ospan
 
-    po = cpts.to(dtype).requires_grad_()
+    po = cpts.detach().to(dtype).clone().requires_grad_()
     e, _ = ospan.e_fc(po, onrm.to(dtype), cog.to(dtype), k=k, box_form=box_form)
     nit = oqp.LAST["n_iter"]
     e.sum().backward()

@@ -67,6 +67,12 @@ def _origin(elem) -> np.ndarray:
     return T
 
 
+def load_mesh_triangles(path: str) -> np.ndarray:
+    from .mesh_io import load_mesh_triangles as _load
+
+    return _load(path)
+
+
 def load_obj_triangles(path: str) -> np.ndarray:
     """(F,3,3) float64 triangle corner positions of a Wavefront OBJ, in file order.
 
@@ -404,7 +410,7 @@ def build_hand_spec(
             if not os.path.exists(p):
                 raise FileNotFoundError(p)
             scale = np.array([float(v) for v in (m.get("scale") or "1 1 1").split()])
-            tv = load_obj_triangles(p) * scale
+            tv = load_mesh_triangles(p) * scale  # OBJ / STL / COLLADA (hands/mesh_io.py)
             T = _origin(e)
             tv = tv @ T[:3, :3].T + T[:3, 3]
             tris.append(tv)
@@ -421,15 +427,33 @@ def build_hand_spec(
             cand_pos.append(cp)
             cand_nrm.append(cn)
             cand_link += [li] * len(cp)
-        pt = []
+        pt, sample_n = [], []
         for cand in (cpts.get(lname) or []):  # [mesh file, n]: the patch the reference samples n candidates from
             if isinstance(cand, list) and len(cand) == 2 and isinstance(cand[0], str):
                 pm = os.path.normpath(os.path.join(contact_mesh_root or mesh_path, cand[0]))
                 if os.path.exists(pm):
-                    pv = load_obj_triangles(pm) * last_scale
+                    pv = load_mesh_triangles(pm) * last_scale
                     pt.append(pv @ last_T[:3, :3].T + last_T[:3, 3])
+                    sample_n.append(int(cand[1]))
         patch_chunks.append(np.concatenate(pt, 0) if pt else np.zeros((0, 3, 3)))
         patch_off.append(patch_off[-1] + len(patch_chunks[-1]))
+        if lname not in cinfo and pt and (not cinfo):
+            # a hand WITHOUT the reference's contact_infos.json dump (schunk2): the candidates are sampled here the way
+            # hand_model.py:269-296,333-335 does it -- 1000 surface samples of every contact patch, farthest-point sampling
+            # from the first sample, normal = face normal of the closest link-mesh triangle.  The reference draws the
+            # samples with trimesh (numpy seed 42) and pytorch3d; neither is available, so the sample SET differs:
+            # PARITY UNPINNED for these points (same construction, same counts, same surfaces).
+            from ..utils import meshes as _meshes
+
+            for patch, k in zip(pt, sample_n):
+                pool = _meshes.sample_surface(patch, 1000, seed=42)
+                sel = _meshes.farthest_point_sampling(pool, k)
+                _, _, fi = _meshes.closest_face(sel, tv)
+                nn = np.cross(tv[fi, 1] - tv[fi, 0], tv[fi, 2] - tv[fi, 0])
+                nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-30)
+                cand_pos.append(sel)
+                cand_nrm.append(nn)
+                cand_link += [li] * len(sel)
         if lname in pen_pts and len(pen_pts[lname]) > 0:
             pk = np.asarray(pen_pts[lname], dtype=np.float64)
             if pk.shape[-1] == 4:

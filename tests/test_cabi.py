@@ -62,13 +62,13 @@ def test_hand_specs():
     from graspqp_amd.hands import AVAILABLE_HANDS, get_hand_spec
 
     expect = {"allegro": (16, 14, 92, 25), "shadow_hand": (24, 18, 80, 22), "robotiq3": (11, 12, 48, 12),
-              "ability_hand": (6, 11, 64, 19), "panda": (1, 3, 16, 2)}
+              "ability_hand": (6, 11, 64, 19), "panda": (1, 3, 16, 2), "schunk2": (1, 7, 16, 0)}
     assert sorted(AVAILABLE_HANDS) == sorted(expect)
     for h in AVAILABLE_HANDS:
         s = get_hand_spec(h)
         assert (s.n_dofs, s.n_links, s.n_contact_candidates, s.n_spheres) == expect[h]
         assert (s.node_parent < np.arange(s.n_nodes)).all()
-        assert s.coupling.shape == (s.n_nodes, s.n_dofs) and s.is_coupled == (h in ("ability_hand", "panda"))
+        assert s.coupling.shape == (s.n_nodes, s.n_dofs) and s.is_coupled == (h in ("ability_hand", "panda", "schunk2"))
         assert np.allclose(np.linalg.norm(s.cand_nrm, axis=1), 1.0, atol=1e-4)
         assert (s.joints_lower < s.joints_upper).all()
 
@@ -237,6 +237,92 @@ def test_coupled_hands_and_grasp_types():
     with pytest.raises(ValueError):
         get_hand_spec("allegro", grasp_type="no_such_type")
     assert get_hand_spec("allegro", grasp_type="all").n_contact_candidates == 92
+
+
+def test_schunk_gripper_spec_and_mesh_readers(tmp_path):
+    """reference hands/schunk.py:12-37,66-83 + assets/schunk_2f: one actuated prismatic joint, the other finger mirrors it
+    (theta, -theta); collision meshes only, read from binary STL and COLLADA (hands/mesh_io.py); 2 x 8 contact candidates
+    sampled on the contact patches at set-up (no dump in the reference: parity unpinned, checked by construction)."""
+    from graspqp_amd.hands import get_hand_spec, mesh_io
+    from graspqp_amd.utils import meshes
+
+    s = get_hand_spec("schunk2")
+    assert s.n_dofs == 1 and s.joint_names == ["egu_50_prismatic_1"]
+    assert s.full_joint_names == ["egu_50_prismatic_1", "egu_50_prismatic_2"] and s.is_coupled
+    np.testing.assert_allclose(s.full_joint_angles(np.array([[0.01]]))[0], [0.01, -0.01])
+    assert list(s.node_type) == [2, 2]  # prismatic
+    np.testing.assert_allclose([s.joints_lower[0], s.joints_upper[0]], [-0.012, 0.039], rtol=1e-6)
+    assert s.link_names == ["egu_50_base_link", "egu_50_translational_left", "egu_50_base_link_left", "egu_50_finger_down",
+                            "egu_50_translational_right", "egu_50_base_link_right", "egu_50_finger_up"]
+    assert [s.link_faces(l).shape[0] for l in range(s.n_links)] == [4520, 1720, 2088, 3272, 1720, 2088, 3272]
+    assert s.n_spheres == 0 and s.n_contact_candidates == 16
+    fingers = {s.link_names[l] for l in np.unique(s.cand_link)}
+    assert fingers == {"egu_50_finger_down", "egu_50_finger_up"} and (np.bincount(s.cand_link)[[3, 6]] == 8).all()
+    np.testing.assert_allclose(np.linalg.norm(s.cand_nrm, axis=1), 1.0, rtol=1e-5)
+    for l in (3, 6):  # every candidate lies on its link's contact patch and on the link mesh; the normal is that face's
+        sel = s.cand_link == l
+        patch = s.patch_verts[s.patch_face_offset[l]:s.patch_face_offset[l + 1]].astype(np.float64)
+        assert len(patch) in (24, 32)  # gripper_finger_down / _up patches
+        _, d_patch, _ = meshes.closest_face(s.cand_pos[sel].astype(np.float64), patch)
+        _, d_mesh, fi = meshes.closest_face(s.cand_pos[sel].astype(np.float64), s.link_faces(l).astype(np.float64))
+        assert d_patch.max() < 1e-6 and d_mesh.max() < 1e-5
+        fv = s.link_faces(l).astype(np.float64)
+        nn = np.cross(fv[fi, 1] - fv[fi, 0], fv[fi, 2] - fv[fi, 0])
+        nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+        assert (np.abs((nn * s.cand_nrm[sel]).sum(1)) > 1 - 1e-5).all()
+    # the finger meshes open along +-x of the base: a positive joint value moves finger_down and finger_up apart symmetrically
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    from ref_cpu import kin as okin
+
+    T0 = okin.forward_kinematics(s, torch.tensor([[0.0]], dtype=torch.float64))[0]
+    T1 = okin.forward_kinematics(s, torch.tensor([[0.02]], dtype=torch.float64))[0]
+    move = (T1[:, :3, 3] - T0[:, :3, 3]).numpy()
+    np.testing.assert_allclose(move[3], -move[6], atol=1e-12)
+    assert abs(np.linalg.norm(move[3]) - 0.02) < 1e-9 and np.abs(move[0]).max() == 0
+    # readers: ASCII STL == binary STL; a COLLADA scene with a scaled + rotated node chain, <polylist> quads and a <translate>
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 1], [1, 0, 1], [0, 2, 1]]], dtype=np.float32)
+    rec = np.zeros(2, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    rec["v"] = tri
+    (tmp_path / "b.stl").write_bytes(b"\0" * 80 + np.uint32(2).tobytes() + rec.tobytes())
+    txt = "solid t\n" + "".join("facet normal 0 0 1\nouter loop\n" + "".join(f"vertex {v[0]} {v[1]} {v[2]}\n" for v in t)
+                                + "endloop\nendfacet\n" for t in tri) + "endsolid t\n"
+    (tmp_path / "a.stl").write_text(txt)
+    np.testing.assert_array_equal(mesh_io.load_mesh_triangles(str(tmp_path / "b.stl")), tri.astype(np.float64))
+    np.testing.assert_array_equal(mesh_io.load_mesh_triangles(str(tmp_path / "a.stl")), tri.astype(np.float64))
+    dae = """<?xml version="1.0"?><COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+<asset><unit name="inch" meter="0.0254"/><up_axis>Z_UP</up_axis></asset>
+<library_geometries><geometry id="g"><mesh>
+<source id="p"><float_array id="pa" count="12">0 0 0 1 0 0 1 1 0 0 1 0</float_array>
+<technique_common><accessor source="#pa" count="4" stride="3"/></technique_common></source>
+<vertices id="v"><input semantic="POSITION" source="#p"/></vertices>
+<polylist count="1"><input semantic="VERTEX" source="#v" offset="0"/><input semantic="NORMAL" source="#p" offset="1"/>
+<vcount>4</vcount><p>0 0 1 0 2 0 3 0</p></polylist></mesh></geometry></library_geometries>
+<library_visual_scenes><visual_scene id="s"><node id="a"><matrix>2 0 0 0 0 2 0 0 0 0 2 0 0 0 0 1</matrix>
+<node id="b"><translate>0 0 5</translate><rotate>0 0 1 90</rotate><instance_geometry url="#g"/></node></node></visual_scene>
+</library_visual_scenes><scene><instance_visual_scene url="#s"/></scene></COLLADA>"""
+    (tmp_path / "q.dae").write_text(dae)
+    got = mesh_io.load_mesh_triangles(str(tmp_path / "q.dae"))
+    # quad fan (0,1,2),(0,2,3); p -> 2 * (Rz(90) p + (0,0,5)); the <unit> is metadata only (as in trimesh)
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=np.float64)
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    want = 2 * (quad @ Rz.T + np.array([0, 0, 5.0]))
+    np.testing.assert_allclose(got, want[[[0, 1, 2], [0, 2, 3]]], atol=1e-12)
+    ref = "/root/reference/graspqp/assets/schunk_2f"
+    if os.path.isdir(ref):  # build container: the packaged spec == a rebuild from the reference's files, and the COLLADA
+        # reader's node-chain handling (0.0254 scale x axis swap) against the extents of the STL twin shipped for the same link
+        r = get_hand_spec("schunk2", os.path.dirname(ref))
+        for f in ("face_verts", "cand_pos", "cand_nrm", "cand_link", "node_pre", "coupling", "link_offset"):
+            np.testing.assert_array_equal(getattr(r, f), getattr(s, f))
+        for stem in ("gripper_finger_down", "base_link"):
+            a = mesh_io.load_mesh_triangles(f"{ref}/meshes/collisions/{stem}.dae")
+            b = mesh_io.load_mesh_triangles(f"{ref}/meshes/collisions/{stem}.STL")
+            np.testing.assert_allclose(a.reshape(-1, 3).min(0), b.reshape(-1, 3).min(0), atol=2e-6)
+            np.testing.assert_allclose(a.reshape(-1, 3).max(0), b.reshape(-1, 3).max(0), atol=2e-6)
+            # (the STL twins are re-meshed hulls without the screw holes: same extents, not the same area)
 
 
 def test_contact_patches_and_grasp_types_asking_for_more_candidates():

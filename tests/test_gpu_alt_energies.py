@@ -232,13 +232,14 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
 # coupled-joint hands and grasp-type subsets
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("hand_name,grasp_type", [("ability_hand", None), ("panda", None), ("allegro", "pinch"),
-                                                  ("ability_hand", "precision"), ("shadow_hand", "pinch")])
+                                                  ("ability_hand", "precision"), ("shadow_hand", "pinch"), ("schunk2", None)])
 def test_coupled_hands_and_grasp_types_whole_iteration(gq, hand_name, grasp_type):
     """Energy + gradient of the whole composition for hands whose tree joints follow fewer actuated ones (ability_hand:
-    q2 = 1.0585 q1 on four fingers; panda: both fingers on one value -- reference hands/ability_hand.py, panda.py) and
+    q2 = 1.0585 q1 on four fingers; panda: both fingers on one value; schunk2: (theta, -theta) prismatic fingers, STL + COLLADA
+    link meshes, no penetration spheres -- reference hands/ability_hand.py, panda.py, schunk.py) and
     for grasp-type contact subsets, against the fp64 oracle; then iterations (graph == eager)."""
     spec = get_hand_spec(hand_name, grasp_type=grasp_type)
-    n_obj, be, n = 2, 5, 4 if hand_name == "panda" else 12
+    n_obj, be, n = 2, 5, 4 if hand_name in ("panda", "schunk2") else 12
     B = n_obj * be
     fvs = [meshes.superquadric(9 + i, 32, 16) for i in range(n_obj)]
     sps = [meshes.surface_points(f, 600, oversample=4, seed=3 + i) for i, f in enumerate(fvs)]

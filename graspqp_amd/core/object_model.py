@@ -64,7 +64,10 @@ class ObjectModel:
             fvs.append(fv.astype(np.float32))
         self.initialize_from_meshes(fvs, object_code_list)
 
-    def initialize_from_meshes(self, face_verts_list, object_code_list=None, surface_points_list=None):
+    def initialize_from_meshes(self, face_verts_list, object_code_list=None, surface_points_list=None, generator=None):
+        """``surface_points_list`` None: the ``num_samples`` surface points of every object are drawn ON THE DEVICE the way
+        the reference does (object_model.py:163-178: 100 x num_samples area-weighted samples, farthest-point sampling
+        from sample 0; ``gq_surface_fps``), then Morton-ordered; a list injects them (tests, fixed workloads)."""
         self.object_code_list = object_code_list or [f"obj{i}" for i in range(len(face_verts_list))]
         self.object_mesh_list = [np.asarray(f, dtype=np.float32) for f in face_verts_list]
         self.object_face_verts_list = [torch.tensor(f, device=self.device) for f in self.object_mesh_list]
@@ -73,8 +76,9 @@ class ObjectModel:
         self.object_scale_tensor = torch.ones(n_obj, self.batch_size_each, device=self.device)  # scale_choice = [1.0]
         if self.num_samples != 0:
             if surface_points_list is None:
-                surface_points_list = [mesh_utils.surface_points(f, self.num_samples) for f in self.object_mesh_list]
-            sp = torch.tensor(np.stack(surface_points_list), dtype=torch.float32, device=self.device)
+                sp = ops.morton_sort_points(ops.surface_fps(self.object_mesh_list, self.num_samples, 100, generator, device=self.device))
+            else:
+                sp = torch.tensor(np.stack(surface_points_list), dtype=torch.float32, device=self.device)
             self.surface_points_each = sp.contiguous()
             self.surface_points_tensor = sp.repeat_interleave(self.batch_size_each, dim=0)
         self._cog = None

@@ -257,4 +257,52 @@ int gq_init_convex_hull(const gqInitDesc* d, void* stream) {
   return GQ_OK;
 }
 
+// Surface samples of the object meshes (reference core/object_model.py:163-178: pytorch3d sample_points_from_meshes with
+// 100 x num_samples points, then sample_farthest_points down to num_samples, first point = sample 0): the two kernels of
+// the hull initialisation with inflate = 0 on the object's own faces, then a gather of the picked samples.
+__global__ void gq_gather_points_kernel(const float* __restrict__ pts, const int32_t* __restrict__ sel, int M, int K,
+                                        float* __restrict__ out) {
+  const int obj = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  const float* p = pts + ((size_t)obj * M + sel[(size_t)obj * K + i]) * 3;
+  float* o = out + ((size_t)obj * K + i) * 3;
+  o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+
+int gq_surface_fps(const float* face_verts, const float* area_cdf, const int32_t* face_offsets, int64_t n_obj,
+                   int64_t samples_per_object, int64_t n_keep, const float* u_face, const float* u_len, float* points_out,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  GQ_REQUIRE(face_verts && area_cdf && face_offsets && u_face && u_len && points_out && workspace,
+             "surface_fps: null pointer");
+  GQ_REQUIRE(n_obj > 0 && n_keep > 0 && samples_per_object >= n_keep && samples_per_object < (1ll << 30),
+             "surface_fps: bad sizes (n_obj=%lld, samples=%lld, keep=%lld)", (long long)n_obj, (long long)samples_per_object,
+             (long long)n_keep);
+  size_t need = 0;
+  gq_init_workspace_bytes(n_obj, samples_per_object, n_keep, &need);
+  GQ_REQUIRE(workspace_bytes >= need, "surface_fps: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  GqInitArgs a{};
+  a.hull_fv = face_verts;
+  a.hull_cdf = area_cdf;
+  a.hull_off = face_offsets;
+  a.n_obj = (int)n_obj;
+  a.M = (int)samples_per_object;
+  a.K = (int)n_keep;
+  a.inflate = 0.0f;
+  a.u_face = u_face;
+  a.u_len = u_len;
+  a.pts = (float*)workspace;
+  a.nrm = a.pts + (size_t)a.n_obj * a.M * 3;
+  a.mind = a.nrm + (size_t)a.n_obj * a.M * 3;
+  a.sel = (int32_t*)(a.mind + (size_t)a.n_obj * a.M);
+  hipLaunchKernelGGL(gq_init_sample_kernel, dim3((unsigned)((a.M + 255) / 256), (unsigned)a.n_obj), dim3(256), 0, st, a);
+  GQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gq_init_fps_kernel, dim3((unsigned)a.n_obj), dim3(1024), 0, st, a);
+  GQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gq_gather_points_kernel, dim3((unsigned)((a.K + 255) / 256), (unsigned)a.n_obj), dim3(256), 0, st, a.pts,
+                     a.sel, a.M, a.K, points_out);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
 }  // extern "C"

@@ -76,7 +76,8 @@ struct GqLr {
     GqSmall<M>::factor(L);
   }
   // dx = (Lam + A'A)^-1 rhs
-  __device__ __forceinline__ void solve(const float (&rhs)[NC], float (&dx)[NC]) const {
+  // y_out (optional): the Woodbury vector y, which IS A dx:  A dx = A Lam^-1 rhs - (M - I) y = v - v + y  (M y = v)
+  __device__ __forceinline__ void solve(const float (&rhs)[NC], float (&dx)[NC], float* y_out = nullptr) const {
     double v[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -87,6 +88,10 @@ struct GqLr {
     }
     gq_wave_sums_d<M>(v);
     GqSmall<M>::solve(L, v);
+    if (y_out) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) y_out[i] = (float)v[i];
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       double num = (double)rhs[c];
@@ -95,17 +100,23 @@ struct GqLr {
       dx[c] = (float)(num * il[c]);
     }
   }
-  // Q x = A'(A x) + ridge x
-  __device__ __forceinline__ void matvec(const float (&x)[NC], float (&out)[NC]) const {
+  // Q x = A'(A x) + ridge x;  ax_known: A x carried along by the caller (A x_new = A x + alpha A dx, A dx = y) instead of
+  // being re-reduced over the wavefront
+  __device__ __forceinline__ void matvec(const float (&x)[NC], float (&out)[NC], const float* ax_known = nullptr) const {
     float ax[M];
+    if (ax_known) {
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      float s = 0.0f;
+      for (int i = 0; i < M; ++i) ax[i] = ax_known[i];
+    } else {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) s = fmaf(a[c][i], x[c], s);
-      ax[i] = s;
+      for (int i = 0; i < M; ++i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s = fmaf(a[c][i], x[c], s);
+        ax[i] = s;
+      }
+      gq_wave_sums_f<M>(ax);
     }
-    gq_wave_sums_f<M>(ax);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       float s = ridge * x[c];
@@ -128,14 +139,15 @@ template <int M, int NC>
 __device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du)[NC], const float (&dl)[NC],
                                           const float (&idu)[NC], const float (&idl)[NC], const float (&rx)[NC], const float (&rsu)[NC], const float (&rsl)[NC],
                                           const float (&rzu)[NC], const float (&rzl)[NC], float (&dx)[NC],
-                                          float (&dsu)[NC], float (&dsl)[NC], float (&dzu)[NC], float (&dzl)[NC]) {
+                                          float (&dsu)[NC], float (&dsl)[NC], float (&dzu)[NC], float (&dzl)[NC],
+                                          float* y_out = nullptr) {
   float rhs[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float tu = du[c] * rzu[c] - rsu[c], tl = dl[c] * rzl[c] - rsl[c];
     rhs[c] = -rx[c] - (tu - tl);
   }
-  S.solve(rhs, dx);
+  S.solve(rhs, dx, y_out);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     dzu[c] = du[c] * (dx[c] + rzu[c]) - rsu[c];
@@ -197,9 +209,18 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
   }
 
   float best = 0.0f;
+#ifdef GQ_QP_CARRY_AX
+  float ax_c[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) ax_c[i] = 0.0f;
+#endif
   for (int it = 0; it < g.max_iter; ++it) {
     float Qx[NC], rx[NC], rzu[NC], rzl[NC];
+#ifdef GQ_QP_CARRY_AX  // A/B: A x carried in scalar registers from the second iteration on (changes the last bits of rx)
+    S.matvec(x, Qx, it > 0 ? ax_c : nullptr);
+#else
     S.matvec(x, Qx);
+#endif
     float a_sz = 0.0f, a_rz = 0.0f, a_rx = 0.0f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -256,7 +277,22 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
     }
     S.factor(lam, live);
     float dxa[NC], dsua[NC], dsla[NC], dzua[NC], dzla[NC];
+#ifdef GQ_QP_CARRY_AX
+    float ya[M], yc[M];
+    if (it == 0) {  // A x of the initial point: reduced once
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sacc = fmaf(S.a[c][i], x[c], sacc);
+        ax_c[i] = sacc;
+      }
+      gq_wave_sums_f<M>(ax_c);
+    }
+    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla, ya);
+#else
     gq_lr_kkt<M, NC>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
+#endif
     float st = GQ_INF;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -278,7 +314,11 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
       rs2l[c] = (-mu * sig + dsla[c] * dzla[c]) * isl[c];
     }
     float dxc[NC], dsuc[NC], dslc[NC], dzuc[NC], dzlc[NC];
+#ifdef GQ_QP_CARRY_AX
+    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc, yc);
+#else
     gq_lr_kkt<M, NC>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc);
+#endif
     st = GQ_INF;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -292,6 +332,11 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
                                      gq_nanmin(gq_step_ratio_rcp(su[c], dsua[c]), gq_step_ratio_rcp(sl[c], dsla[c]))));
     }
     alpha = gq_nanmin(0.999f * gq_dpp_nanmin(st), 1.0f);
+#ifdef GQ_QP_CARRY_AX
+#pragma unroll
+    for (int i = 0; i < M; ++i)  // wave-uniform: kept in scalar registers
+      ax_c[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fmaf(alpha, ya[i] + yc[i], ax_c[i]))));
+#endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (live[c]) {

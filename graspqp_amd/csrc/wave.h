@@ -60,6 +60,16 @@ __device__ __forceinline__ void gq_wave_sums_d(double (&v)[K]) {
   for (int i = 0; i < K1; ++i) s1[i] = gq_fold32_d(v[2 * i], (2 * i + 1 < K) ? v[2 * i + 1] : 0.0);
 #pragma unroll
   for (int i = 0; i < K2; ++i) s2[i] = gq_fold16_d(s1[2 * i], (2 * i + 1 < K1) ? s1[2 * i + 1] : 0.0);
+#ifdef GQ_SUMS_STAGE_MAJOR  // A/B: the K2 independent chains advance stage by stage (fills DPP hazard slots with other chains)
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_d<0xb1>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_d<0x4e>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_d<0x141>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_d<0x140>(s2[i]);
+#else
 #pragma unroll
   for (int i = 0; i < K2; ++i) {
     double t = s2[i];
@@ -69,6 +79,7 @@ __device__ __forceinline__ void gq_wave_sums_d(double (&v)[K]) {
     t += gq_dpp_all_d<0x140>(t);  // row_mirror
     s2[i] = t;
   }
+#endif
   // row r of s2[i] now holds: r=0 -> v[4i], r=1 -> v[4i+2], r=2 -> v[4i+1], r=3 -> v[4i+3]
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -100,6 +111,16 @@ __device__ __forceinline__ void gq_wave_sums_f(float (&v)[K]) {
   for (int i = 0; i < K1; ++i) s1[i] = gq_fold32_f(v[2 * i], (2 * i + 1 < K) ? v[2 * i + 1] : 0.0f);
 #pragma unroll
   for (int i = 0; i < K2; ++i) s2[i] = gq_fold16_f(s1[2 * i], (2 * i + 1 < K1) ? s1[2 * i + 1] : 0.0f);
+#ifdef GQ_SUMS_STAGE_MAJOR
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_f<0xb1>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_f<0x4e>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_f<0x141>(s2[i]);
+#pragma unroll
+  for (int i = 0; i < K2; ++i) s2[i] += gq_dpp_all_f<0x140>(s2[i]);
+#else
 #pragma unroll
   for (int i = 0; i < K2; ++i) {
     float t = s2[i];
@@ -109,6 +130,7 @@ __device__ __forceinline__ void gq_wave_sums_f(float (&v)[K]) {
     t += gq_dpp_all_f<0x140>(t);  // row_mirror
     s2[i] = t;
   }
+#endif
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int i = k / 4, q = k % 4;

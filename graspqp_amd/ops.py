@@ -91,6 +91,45 @@ class MeshSet:
             pass
 
 
+def surface_fps(face_verts_list, n_keep: int, oversample: int = 100, generator=None, draws=None, device="cuda") -> torch.Tensor:
+    """(n_obj, n_keep, 3) surface samples of every mesh, drawn on the device (reference core/object_model.py:163-178):
+    ``oversample * n_keep`` area-weighted samples per mesh, farthest-point sampling from sample 0 down to ``n_keep``.
+    ``draws`` = (u_face (n_obj,M), u_len (n_obj,M,2)) injects the uniforms (tests)."""
+    dev = torch.device(device)
+    fvs = [torch.as_tensor(f, dtype=torch.float32).reshape(-1, 3, 3).to(dev) for f in face_verts_list]
+    n_obj, M = len(fvs), int(oversample) * int(n_keep)
+    cdfs, off = [], [0]
+    for f in fvs:
+        area = 0.5 * torch.linalg.cross(f[:, 1] - f[:, 0], f[:, 2] - f[:, 0]).double().norm(dim=1)
+        c = torch.cumsum(area, 0)
+        cdfs.append((c / c[-1]).float())
+        off.append(off[-1] + f.shape[0])
+    fv, cdf = torch.cat(fvs).contiguous(), torch.cat(cdfs).contiguous()
+    offs = torch.tensor(off, dtype=torch.int32, device=dev)
+    if draws is None:
+        draws = (torch.rand(n_obj, M, device=dev, generator=generator), torch.rand(n_obj, M, 2, device=dev, generator=generator))
+    u_face, u_len = (_c(d.to(dev)) for d in draws)
+    out = torch.empty(n_obj, int(n_keep), 3, device=dev)
+    nb = _size_call("gq_init_workspace_bytes", ctypes.c_int64(n_obj), ctypes.c_int64(M), ctypes.c_int64(int(n_keep)))
+    ws = _ws(nb, dev)
+    _C.call("gq_surface_fps", _C.f32(fv), _C.f32(cdf), _C.i32(offs), ctypes.c_int64(n_obj), ctypes.c_int64(M),
+            ctypes.c_int64(int(n_keep)), _C.f32(u_face), _C.f32(u_len), _C.f32(out), _C.ptr(ws), nb, _C.stream_ptr())
+    return out
+
+
+def morton_sort_points(points: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """(n_obj,P,3) -> the same points, every object's set ordered along a 3-D Morton curve (neighbouring indices are
+    spatial neighbours: the 64 points of a wavefront of the penetration query then meet the same hand links)."""
+    lo, hi = points.amin(dim=1, keepdim=True), points.amax(dim=1, keepdim=True)
+    q = ((points - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).to(torch.int64)
+    code = torch.zeros(points.shape[:2], dtype=torch.int64, device=points.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[..., a] >> b) & 1) << (3 * b + a)
+    order = torch.argsort(code, dim=1, stable=True)
+    return torch.gather(points, 1, order.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+
+
 class PointGrid:
     """Coarse uniform grid over the surface points of every object (n_obj,P,3): set-up data of the link-driven
     penetration query (gq_hand_pen_forward_cells)."""

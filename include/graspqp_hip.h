@@ -408,6 +408,14 @@ typedef struct gqInitDesc {
 } gqInitDesc;
 int gq_init_workspace_bytes(int64_t n_obj, int64_t samples_per_object, int64_t batch_each, size_t* bytes);
 int gq_init_convex_hull(const gqInitDesc* desc, void* stream);
+/* Surface samples of object meshes on the device (reference core/object_model.py:163-178: pytorch3d
+ * sample_points_from_meshes with 100 x num_samples points, then sample_farthest_points(K = num_samples) starting at sample
+ * 0): face_verts (sumF,3,3) of n_obj meshes, area_cdf (sumF) normalised cumulative face area per mesh, face_offsets
+ * (n_obj+1); u_face (n_obj,M), u_len (n_obj,M,2) uniform draws; points_out (n_obj,n_keep,3).  Workspace:
+ * gq_init_workspace_bytes(n_obj, samples_per_object, n_keep).                                                          */
+int gq_surface_fps(const float* face_verts, const float* area_cdf, const int32_t* face_offsets, int64_t n_obj,
+                   int64_t samples_per_object, int64_t n_keep, const float* u_face, const float* u_len, float* points_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- MALA* optimiser: MalaStar.try_step / accept_step, core/optimizer.py:199-273,289-340; fit.py:403-406,454-458
  * random draws are inputs: u_switch (B,n) U[0,1), new_idx (B,n) in [0,C), u_accept (B) U[0,1).               */

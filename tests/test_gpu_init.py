@@ -63,6 +63,47 @@ def test_init_kernels_match_oracle_on_injected_draws(gq, hand_name):
     np.testing.assert_allclose(pose[:, 9:].cpu().numpy(), pose_o[:, 9:].numpy(), atol=2e-4)
 
 
+def test_object_surface_points_are_sampled_on_the_device(gq):
+    """ObjectModel.initialize (reference object_model.py:163-178): oversampled area-weighted surface samples + farthest-point
+    sampling from sample 0, on the device (gq_surface_fps).  With injected uniforms the picked SET equals the oracle's
+    sample_surface + farthest_points on the same draws; without, the points lie on the mesh, are well spread and reproducible
+    from the generator; ObjectModel stores them Morton-ordered."""
+    from graspqp_amd.core.object_model import ObjectModel
+
+    fvs = [meshes.superquadric(50 + i, 32, 16) for i in range(2)]
+    K, over = 200, 20
+    M = K * over
+    g = torch.Generator().manual_seed(3)
+    u_face, u_len = torch.rand(2, M, generator=g), torch.rand(2, M, 2, generator=g)
+    pts = gq.ops.surface_fps(fvs, K, over, draws=(u_face, u_len))
+    torch.cuda.synchronize()
+    for i, fv in enumerate(fvs):
+        dense, _ = oinit.sample_surface(fv.astype(np.float64), u_face[i].double(), u_len[i].double())
+        sel = oinit.farthest_points(dense.float().double(), K)
+        want = dense[sel].numpy()
+        got = pts[i].cpu().numpy()
+        # the same points in the same order, except where two candidates tie within fp32 round-off of the distance
+        same = np.linalg.norm(got - want, axis=1) < 1e-5
+        assert same.mean() > 0.97, same.mean()
+        d2, _, _, _ = gq.ops.compute_sdf(pts[i].contiguous(), torch.tensor(fv, device="cuda"))
+        assert float(d2.max()) < 1e-10  # on the surface
+        nn = torch.cdist(pts[i], pts[i]) + 1e3 * torch.eye(K, device="cuda")
+        assert float(nn.min()) > 0.25 * float(nn.min(dim=1).values.median())  # farthest-point spread: no near-duplicates
+    om = ObjectModel(batch_size_each=3, num_samples=300)
+    om.initialize_from_meshes(fvs, generator=torch.Generator(device="cuda").manual_seed(7))
+    om2 = ObjectModel(batch_size_each=3, num_samples=300)
+    om2.initialize_from_meshes(fvs, generator=torch.Generator(device="cuda").manual_seed(7))
+    assert om.surface_points_each.shape == (2, 300, 3) and torch.equal(om.surface_points_each, om2.surface_points_each)
+    assert om.surface_points_tensor.shape == (6, 300, 3)
+    d2, _, _, _ = gq.ops.compute_sdf(om.surface_points_each[1].contiguous(), torch.tensor(fvs[1], device="cuda"))
+    assert float(d2.max()) < 1e-10
+    # Morton order: consecutive points are spatial neighbours (far closer than two random points of the set)
+    p = om.surface_points_each[0]
+    step = (p[1:] - p[:-1]).norm(dim=1).median()
+    rand = (p[torch.randperm(300, device="cuda")] - p).norm(dim=1).median()
+    assert float(step) < 0.35 * float(rand)
+
+
 def test_init_matches_reference_initialize_convex_hull_fixture(gq, golden_dir):
     """Translation and rot6d of all rows against what the reference's own initialize_convex_hull produced from the same
     hull samples and uniform draws (fixture init_*.npz, tools/make_golden.py::gen_init)."""

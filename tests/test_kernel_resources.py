@@ -28,6 +28,8 @@ BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
                                                 # 38 words around the contact query (once per query, not in its loops)
     "gq_stage_b_kernel<1, 4>": (168, 0),
     "gq_hand_pen_bwd_kernel<10>": (128, 0),     # <= 2560 surface points: ten slices per round, 4 wavefronts per SIMD
+    "gq_stage_alt_kernel<1, 2>": (128, 0),      # dexgrasp role + penetration query
+    "gq_stage_alt_kernel<2, 2>": (128, 32),     # tdg role (49 accumulators per thread) capped to the query's occupancy: 5 words spill
 }
 
 
@@ -44,4 +46,5 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert r["scratch"] <= smax, (name, r)
     spilled = {k: v["scratch"] for k, v in res.items() if v["scratch"] > 0}
     assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel<4>", "gq_fc_head_stop_kernel<1>",
-                            "gq_stage_a_kernel<1, true, 2>", "gq_stage_a_kernel<1, true, 1>", "gq_fc_tail_kernel<1, 0>"}, f"new register spills: {spilled}"
+                            "gq_stage_a_kernel<1, true, 2>", "gq_stage_a_kernel<1, true, 1>", "gq_fc_tail_kernel<1, 0>",
+                            "gq_stage_alt_kernel<2, 2>", "gq_stage_alt_kernel<2, 1>"}, f"new register spills: {spilled}"

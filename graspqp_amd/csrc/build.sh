@@ -18,6 +18,7 @@ deps() {  # headers each translation unit includes
     stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h kin_dev.h metric_dev.h" ;;
     qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
     sdf) echo "common.h tri.h pen_dev.h sdf_dev.h wave.h" ;;
+    bvh) echo "common.h tri.h" ;;
     fc) echo "common.h fc_dev.h wave.h" ;;
     loop) echo "common.h fc_dev.h loop_dev.h wave.h" ;;
     metric) echo "common.h wave.h metric_dev.h" ;;
@@ -27,7 +28,7 @@ deps() {  # headers each translation unit includes
     *) echo "common.h" ;;
   esac
 }
-for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf kin fc fcstep stage loop export init metric; do
+for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf bvh kin fc fcstep stage loop export init metric; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done

@@ -91,6 +91,28 @@ class MeshSet:
             pass
 
 
+class Bvh:
+    """Implicit 4-ary box hierarchy over one mesh (csrc/bvh.hip): the acceleration data of compute_sdf for large query
+    counts."""
+
+    def __init__(self, face_verts):
+        fv = np.ascontiguousarray(np.asarray(face_verts, dtype=np.float32).reshape(-1, 3, 3))
+        self.n_faces = int(fv.shape[0])
+        h = ctypes.c_void_p(0)
+        torch.cuda.current_device()
+        _C.call("gq_bvh_create", fv.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(self.n_faces), ctypes.byref(h))
+        self.handle = h
+        self.hid = _register_handle(self)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _C.lib().gq_bvh_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def surface_fps(face_verts_list, n_keep: int, oversample: int = 100, generator=None, draws=None, device="cuda") -> torch.Tensor:
     """(n_obj, n_keep, 3) surface samples of every mesh, drawn on the device (reference core/object_model.py:163-178):
     ``oversample * n_keep`` area-weighted samples per mesh, farthest-point sampling from sample 0 down to ``n_keep``.
@@ -216,30 +238,37 @@ torch.library.register_autograd("graspqp_amd::compute_sdf", _sdf_bwd, setup_cont
 # one per link, object_model.py:146-148 one per object), so the acceleration data of a mesh -- Morton-sorted face records
 # + oriented 64-face cluster boxes (gq_meshset_create) -- is built on the first call with a tensor and kept while that
 # tensor is alive and unmodified (weak reference + data pointer + version counter; a dead tensor drops its entry).
-_MESH_CACHE = {}              # id(face_verts) -> (weakref, data_ptr, _version, MeshSet)
-_MESH_CACHE_MIN_FACES = 1024  # smaller meshes: the face loop of gq_sdf_forward is already the fastest form
-_MESH_CACHE_MAX_BRUTE_N = 65536
+_MESH_CACHE = {}              # (id(face_verts), kind) -> (weakref, data_ptr, _version, MeshSet | Bvh)
+_MESH_CACHE_MIN_FACES = 1024  # cluster search (one wavefront per query): meshes from this size on
+_BVH_MIN_QUERIES = 32768      # box hierarchy (one query per lane): query counts from this size on
+_BVH_MIN_FACES, _BVH_MAX_FACES = 32, 65536
 
 
-def _cached_meshset(face_verts):
-    key = id(face_verts)
+def _cached(face_verts, kind):
+    key = (id(face_verts), kind)
     ent = _MESH_CACHE.get(key)
     if ent is not None and ent[0]() is face_verts and ent[1] == face_verts.data_ptr() and ent[2] == face_verts._version:
         return ent[3]
-    fv = face_verts.detach()
-    ms = MeshSet([fv.to(torch.float32).cpu().numpy()])  # one device->host copy, once per mesh
+    fv = face_verts.detach().to(torch.float32).cpu().numpy()  # one device->host copy, once per mesh and kind
+    obj = MeshSet([fv]) if kind == "clusters" else Bvh(fv)
     ref = weakref.ref(face_verts, lambda _r, k=key: _MESH_CACHE.pop(k, None))
-    _MESH_CACHE[key] = (ref, face_verts.data_ptr(), face_verts._version, ms)
-    return ms
+    _MESH_CACHE[key] = (ref, face_verts.data_ptr(), face_verts._version, obj)
+    return obj
+
+
+def _cached_meshset(face_verts):
+    return _cached(face_verts, "clusters")
 
 
 def compute_sdf(points: torch.Tensor, face_verts: torch.Tensor):
     """torchsdf.compute_sdf drop-in -> (dist_sq, sign int32, normal, closest).
 
-    Two device paths behind the one signature: the cluster best-first search (one wavefront per query) on the cached
-    acceleration data of ``face_verts`` for meshes of >= 1024 faces unless the query count is so large and the mesh so
-    small that the per-lane face loop wins; the face loop of gq_sdf_forward otherwise (its only set-up is one face-record
-    launch per call)."""
+    Three device paths behind the one signature, all exact with the same winner rule (smallest ranking distance, ties to
+    the smallest face index): (i) N >= 32768 queries: one query per lane through the mesh's box hierarchy (gq_sdf_forward_bvh;
+    the per-link calls of HandModel.cal_distance); (ii) fewer queries against >= 1024 faces: best-first search over
+    oriented 64-face cluster boxes, one wavefront per query (the contact queries of ObjectModel.cal_distance); (iii)
+    otherwise the face loop of gq_sdf_forward (no set-up).  (i) and (ii) use acceleration data built on the first call
+    with a ``face_verts`` tensor and kept while that tensor is alive and unmodified."""
     if points.dim() != 2 or points.shape[1] != 3:
         raise ValueError(f"compute_sdf: points must be (N,3), got {tuple(points.shape)}")
     if face_verts.dim() != 3 or tuple(face_verts.shape[1:]) != (3, 3):
@@ -247,10 +276,11 @@ def compute_sdf(points: torch.Tensor, face_verts: torch.Tensor):
     if not points.is_cuda:
         raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
     N, F = points.shape[0], face_verts.shape[0]
-    # per query: ~64k lane-instruction slots for the wavefront search against 45 F for the face loop, which however needs
-    # N / 64 >> 1024 wavefronts to fill the chip
-    if N > 0 and F >= _MESH_CACHE_MIN_FACES and not face_verts.requires_grad and (N < _MESH_CACHE_MAX_BRUTE_N or F > 1400):
-        return torch.ops.graspqp_amd.sdf_meshset(points, _cached_meshset(face_verts).hid, N)
+    if N > 0 and not face_verts.requires_grad:
+        if N >= _BVH_MIN_QUERIES and _BVH_MIN_FACES <= F <= _BVH_MAX_FACES:
+            return torch.ops.graspqp_amd.sdf_bvh(points, _cached(face_verts, "bvh").hid)
+        if F >= _MESH_CACHE_MIN_FACES:
+            return torch.ops.graspqp_amd.sdf_meshset(points, _cached_meshset(face_verts).hid, N)
     return torch.ops.graspqp_amd.compute_sdf(points, face_verts)
 
 
@@ -281,6 +311,29 @@ def _sdf_ms_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
 
 
 torch.library.register_autograd("graspqp_amd::sdf_meshset", _sdf_ms_bwd, setup_context=_sdf_ms_setup)
+
+
+@_custom_op("graspqp_amd::sdf_bvh", mutates_args=(), device_types="cuda")
+def _sdf_bvh_op(points: Tensor, bvh: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """compute_sdf of many points against one mesh through its box hierarchy (one query per lane)."""
+    pts = _c(points).reshape(-1, 3)
+    d2, sgn, nrm, cls = _sdf_outputs(pts)
+    _C.call("gq_sdf_forward_bvh", _handle(bvh).handle, _C.f32(pts), pts.shape[0], _C.f32(d2), _C.i32(sgn), _C.f32(nrm),
+            _C.f32(cls), _C.stream_ptr())
+    return d2, sgn, nrm, cls
+
+
+@_sdf_bvh_op.register_fake
+def _(points, bvh):
+    return _sdf_outputs(points.reshape(-1, 3))
+
+
+def _sdf_bvh_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
+    pts, cls = ctx.saved_tensors
+    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None
+
+
+torch.library.register_autograd("graspqp_amd::sdf_bvh", _sdf_bvh_bwd, setup_context=_sdf_ms_setup)
 
 
 def sdf_meshset(points, meshset: MeshSet, queries_per_mesh: int):

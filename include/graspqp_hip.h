@@ -48,6 +48,16 @@ int gq_sdf_forward(const float* points /* (N,3) */, int64_t n_points, const floa
 /* object_model.py:217-220: query q uses mesh q / queries_per_mesh (one mesh per object) */
 int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_points, int64_t queries_per_mesh,
                            float* dist_sq, int32_t* sign, float* normal, float* closest, void* stream);
+/* The same query for MANY points against ONE mesh (the per-link calls of HandModel.cal_distance, core/hand_model.py:
+ * 914-953: batch * 2500 surface points per call): one query per lane through an implicit 4-ary box hierarchy over the
+ * Morton-sorted faces, staged in LDS when it fits (csrc/bvh.hip).  Exact (same winner rule as gq_sdf_forward: smallest
+ * ranking distance, ties to the smallest face index; the winner is finished exactly).  gq_bvh_create takes HOST triangles
+ * (n_faces,3,3), 1 <= n_faces <= 65536.                                                                                 */
+typedef struct gqBvh gqBvh;
+int gq_bvh_create(const float* face_verts_host, int64_t n_faces, gqBvh** out);
+int gq_bvh_destroy(gqBvh* bvh);
+int gq_sdf_forward_bvh(const gqBvh* bvh, const float* points, int64_t n_points, float* dist_sq, int32_t* sign,
+                       float* normal /* or NULL */, float* closest, void* stream);
 int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float* closest, int64_t n_points,
                     float* grad_points, void* stream);
 

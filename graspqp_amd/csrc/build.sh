@@ -15,6 +15,7 @@ echo "$SIG" > "$OUT/.flags"
 deps() {  # headers each translation unit includes
   case "$1" in
     qp_lr|fcstep) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h" ;;
+    qp_dense) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h" ;;
     stage) echo "common.h qp_core.h qp_kernels.h qp_lr.h wave.h fc_dev.h fcstep_dev.h pen_dev.h tri.h kin_dev.h metric_dev.h" ;;
     qp|qp_nz*) echo "common.h qp_core.h qp_kernels.h" ;;
     sdf) echo "common.h tri.h pen_dev.h sdf_dev.h wave.h" ;;
@@ -28,7 +29,7 @@ deps() {  # headers each translation unit includes
     *) echo "common.h" ;;
   esac
 }
-for f in api qp qp_lr qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf bvh kin fc fcstep stage loop export init metric; do
+for f in api qp qp_lr qp_dense qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf bvh kin fc fcstep stage loop export init metric; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done

@@ -302,8 +302,12 @@ static void gq_qp_stop_dispatch(const float* resid, const float* mu, int B, int 
                        n_iter);
 }
 
+int gq_qp_launch_iter_dense_lds(const GqQpArgs& a, hipStream_t st);    // qp_dense.hip: dense Q, 65..128 variables
+int gq_qp_launch_bwd_dense_lds(const GqQpBwdArgs& a, hipStream_t st);
+
 static int gq_launch_iter(const GqQpArgs& a, int mode, hipStream_t st) {
   if (mode == 0) return gq_qp_lr_launch_iter(a, st);
+  if (a.nz > 64) return gq_qp_launch_iter_dense_lds(a, st);
   if (a.nz <= 16) return gq_qp_launch_iter_16(a, mode, st);
   if (a.nz <= 32) return gq_qp_launch_iter_32(a, mode, st);
   if (a.nz <= 48) return gq_qp_launch_iter_48(a, mode, st);
@@ -311,6 +315,7 @@ static int gq_launch_iter(const GqQpArgs& a, int mode, hipStream_t st) {
 }
 static int gq_launch_bwd(const GqQpBwdArgs& a, int mode, hipStream_t st) {
   if (mode == 0) return gq_qp_lr_launch_bwd(a, st);
+  if (a.nz > 64) return gq_qp_launch_bwd_dense_lds(a, st);
   if (a.nz <= 16) return gq_qp_launch_bwd_16(a, mode, st);
   if (a.nz <= 32) return gq_qp_launch_bwd_32(a, mode, st);
   if (a.nz <= 48) return gq_qp_launch_bwd_48(a, mode, st);
@@ -320,7 +325,7 @@ static int gq_launch_bwd(const GqQpBwdArgs& a, int mode, hipStream_t st) {
 static int gq_qp_forward_common(GqQpArgs a, float eps, int not_improved_lim, float* x, float* lam, float* slack,
                                 int* best_iter, int* n_iter, void* ws, size_t ws_bytes, hipStream_t st, int mode) {
   GQ_REQUIRE(a.B > 0 && a.nz > 0, "boxqp: empty batch (B=%d nz=%d)", a.B, a.nz);
-  GQ_REQUIRE(a.nz <= (mode == 0 ? 128 : 64), "boxqp: nz=%d exceeds the supported size (%d)", a.nz, mode == 0 ? 128 : 64);
+  GQ_REQUIRE(a.nz <= 128, "boxqp: nz=%d exceeds the supported size (128)", a.nz);
   GQ_REQUIRE(a.max_iter >= 1 && a.max_iter <= 64, "boxqp: max_iter=%d out of range", a.max_iter);
   GQ_REQUIRE(mode == 1 || (a.m >= 1 && a.m <= 8), "boxqp: m=%d must be in [1,8]", a.m);
   GQ_REQUIRE(ws, "boxqp: null workspace pointer");
@@ -486,7 +491,7 @@ int gq_lsq_boxqp_backward(const float* A, const float* lam, const float* slack, 
 int gq_boxqp_backward(const float* Q, const float* lam, const float* slack, const float* grad_x, int64_t batch, int nz,
                       float* dx, float* dlam, void* stream) {
   GQ_REQUIRE(Q && lam && slack && grad_x && dx && dlam, "boxqp_backward: null pointer");
-  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 64, "boxqp_backward: bad sizes B=%lld nz=%d", (long long)batch, nz);
+  GQ_REQUIRE(batch > 0 && nz > 0 && nz <= 128, "boxqp_backward: bad sizes B=%lld nz=%d", (long long)batch, nz);
   GqQpBwdArgs a{};
   a.Q = Q;
   a.lam = lam;

@@ -135,8 +135,8 @@ __device__ __forceinline__ float gq_step_ratio_rcp(float v, float dv) {
 }
 
 // reduced-KKT solve for my columns (see gq_kkt_solve in qp_core.h)
-template <int M, int NC>
-__device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du)[NC], const float (&dl)[NC],
+template <int M, int NC, class SOLVER = GqLr<M, NC>>
+__device__ __forceinline__ void gq_lr_kkt(const SOLVER& S, const float (&du)[NC], const float (&dl)[NC],
                                           const float (&idu)[NC], const float (&idl)[NC], const float (&rx)[NC], const float (&rsu)[NC], const float (&rsl)[NC],
                                           const float (&rzu)[NC], const float (&rzl)[NC], float (&dx)[NC],
                                           float (&dsu)[NC], float (&dsl)[NC], float (&dzu)[NC], float (&dzl)[NC],
@@ -157,9 +157,11 @@ __device__ __forceinline__ void gq_lr_kkt(const GqLr<M, NC>& S, const float (&du
   }
 }
 
-// All PDIPM iterations of one problem; S.a (my columns of A) and S.ridge are set by the caller.
-template <int M, int NC>
-__device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int lane, GqLr<M, NC>& S,
+// All PDIPM iterations of one problem; S.a (my columns of A) and S.ridge are set by the caller.  SOLVER: anything with
+// factor(lam, live) / solve(rhs, dx[, y_out]) / matvec(x, out) for (Q + diag(lam - g.ridge)) -- the low-rank form GqLr (A'A +
+// ridge I by the Woodbury identity) or the dense LDS form of qp_dense_lds.h (any SPD Q, g.ridge = 0)
+template <int M, int NC, class SOLVER = GqLr<M, NC>>
+__device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int lane, SOLVER& S,
                                                  const bool (&live)[NC], const float (&p)[NC], const float (&hu)[NC],
                                                  const float (&hl)[NC], float* hist_resid = nullptr,
                                                  float* hist_mu = nullptr) {
@@ -179,7 +181,7 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
   }
   // ---- initial point: solve_kkt(d = 1, rx = p, rs = 0, rz = -h) ----------------------------------------------
   S.factor(lam, live);
-  gq_lr_kkt<M, NC>(S, ones, ones, ones, ones, p, zero, zero, nhu, nhl, x, su, sl, zu, zl);
+  gq_lr_kkt<M, NC, SOLVER>(S, ones, ones, ones, ones, p, zero, zero, nhu, nhl, x, su, sl, zu, zl);
   {
     float ms = GQ_INF, mz = GQ_INF;
 #pragma unroll
@@ -289,9 +291,9 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
       }
       gq_wave_sums_f<M>(ax_c);
     }
-    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla, ya);
+    gq_lr_kkt<M, NC, SOLVER>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla, ya);
 #else
-    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
+    gq_lr_kkt<M, NC, SOLVER>(S, du, dl, idu, idl, rx, zu, zl, rzu, rzl, dxa, dsua, dsla, dzua, dzla);
 #endif
     float st = GQ_INF;
 #pragma unroll
@@ -315,9 +317,9 @@ __device__ __forceinline__ void gq_qp_lr_iterate(const GqQpArgs& g, int row, int
     }
     float dxc[NC], dsuc[NC], dslc[NC], dzuc[NC], dzlc[NC];
 #ifdef GQ_QP_CARRY_AX
-    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc, yc);
+    gq_lr_kkt<M, NC, SOLVER>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc, yc);
 #else
-    gq_lr_kkt<M, NC>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc);
+    gq_lr_kkt<M, NC, SOLVER>(S, du, dl, idu, idl, zero, rs2u, rs2l, zero, zero, dxc, dsuc, dslc, dzuc, dzlc);
 #endif
     st = GQ_INF;
 #pragma unroll

@@ -7,7 +7,7 @@ configs[1]: the same launch on the same state (a) back to back, (b) after the ot
   rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 tools/l2_residency.py pmc      (then)
   python tools/l2_residency.py fold <counter_collection.csv> [...more passes]   -> per-case counter values per launch
 
-The cases are told apart in the counter file by marker kernels (torch fills of distinct sizes) dispatched before each
+The cases are told apart in the counter file by marker launches (gq_fill with distinct grid sizes) dispatched before each
 group.  Development / profiling aid (run on the GPU box).
 """
 import collections
@@ -54,7 +54,7 @@ def run(mode):
     st = setup()
     pose, idx = st.hand_pose.clone(), st.contact_idx.clone()
     junk = torch.empty(64 * 1024 * 1024, device="cuda")
-    mark = [torch.empty(1000 + 7 * i, device="cuda") for i in range(4)]
+    mark = [torch.empty(256 * (10 + i), device="cuda") for i in range(4)]  # gq_fill launches of distinct grid sizes
     stream = _C.stream_ptr()
 
     def fk():
@@ -82,10 +82,10 @@ def run(mode):
     out = {}
     for i, (name, pre) in enumerate((("back_to_back", lambda: None), ("after_the_other_launches_of_an_iteration", others),
                                      ("after_256MB_of_unrelated_traffic", lambda: junk.fill_(1.0)))):
-        mark[i].fill_(float(i))  # marker dispatch: tells the groups apart in the counter file
+        _C.call("gq_fill", _C.f32(mark[i]), float(i), mark[i].numel(), stream)  # marker dispatch: tells the groups apart
         torch.cuda.synchronize()
         out[name] = dict(zip(("us_median", "us_min"), timed(pre)))
-    mark[3].fill_(3.0)
+    _C.call("gq_fill", _C.f32(mark[3]), 3.0, mark[3].numel(), stream)
     torch.cuda.synchronize()
     if mode == "time":
         print(json.dumps({"fk_forward_with_contact_queries_us": out, "reps": REPS - 2}))
@@ -102,13 +102,11 @@ def fold(paths):
         seen = set()
         for r in rows:
             k = r["Kernel_Name"]
-            did = r.get("Dispatch_Id", r.get("Dispatch_ID"))
-            if "gq_" not in k and "fill" in k.lower() or "FillFunctor" in k:
-                # marker fills have grid sizes 1000 / 1007 / 1014 / 1021 elements (the junk fill is far larger)
-                g = int(float(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0))
-                if did not in seen and g < 4096 * 8:
-                    seen.add(did)
-                    group += 1
+            if "gq_fill" in k:  # markers: grid sizes 2560 + 256 i
+                g = int(float(r.get("Grid_Size", 0) or 0))
+                if g in (2560, 2816, 3072, 3328) and r.get("Dispatch_Id") not in seen:
+                    seen.add(r.get("Dispatch_Id"))
+                    group = (g - 2560) // 256
                 continue
             if "gq_fk_forward_kernel" in k and 0 <= group < 3:
                 acc[names[group + 1]][r["Counter_Name"]].append(float(r["Counter_Value"]))

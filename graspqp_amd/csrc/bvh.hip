@@ -25,6 +25,7 @@ struct gqBvh {
   int lvl_off[8];    // word offset of level k's boxes
   int lvl_n[8];      // padded node count of level k
   int fbox_off, rec_off;
+  float centre[3];   // centre of the mesh's bounding box (direction bins of the sorted kernel)
 };
 
 struct GqBvhArgs {
@@ -146,6 +147,112 @@ __global__ __launch_bounds__(512) void gq_sdf_bvh_kernel(GqBvhArgs g) {
   }
 }
 
+// The same traversal with the queries of a 2048-point chunk first ORDERED BY DIRECTION from the mesh centre inside the block
+// (LDS counting sort over 96 direction bins: cube face x 4 x 4 cells): the 64 lanes of a wavefront then walk nearly the same
+// nodes, so their LDS reads coalesce into broadcasts instead of conflicting and the wavefront's cost (its slowest lane)
+// approaches the mean.  The order in which equal-bin queries land on lanes depends on LDS atomics, the result of every
+// query does not.  Results are written back to the query's own slot.
+#define GQ_BVH_CHUNK 2048
+#define GQ_BVH_BINS 96
+__device__ __forceinline__ int gq_bvh_dir_bin(gq3 d) {
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int face;
+  float u, v, m;
+  if (ax >= ay && ax >= az) { face = d.x < 0.0f ? 1 : 0; m = ax; u = d.y; v = d.z; }
+  else if (ay >= az) { face = d.y < 0.0f ? 3 : 2; m = ay; u = d.x; v = d.z; }
+  else { face = d.z < 0.0f ? 5 : 4; m = az; u = d.x; v = d.y; }
+  const float inv = m > 0.0f ? 2.0f / m : 0.0f;  // u / m in [-1, 1] -> cell 0..3
+  int iu = (int)fminf(fmaxf(fmaf(u, inv, 2.0f), 0.0f), 3.0f);
+  int iv = (int)fminf(fmaxf(fmaf(v, inv, 2.0f), 0.0f), 3.0f);
+  if (iv & 1) iu = 3 - iu;  // boustrophedon inside the face: consecutive bins are neighbours
+  return face * 16 + iv * 4 + iu;
+}
+
+template <int DEPTH, bool LDS>
+__global__ __launch_bounds__(512) void gq_sdf_bvh_sorted_kernel(GqBvhArgs g, float cx, float cy, float cz) {
+  extern __shared__ float4 gq_bvh_sh[];
+  __shared__ unsigned s_hist[GQ_BVH_BINS + 32];
+  __shared__ unsigned short s_perm[GQ_BVH_CHUNK];
+  const float4* base = g.blob;
+  if (LDS) {
+    for (unsigned i = threadIdx.x; i < g.words; i += 512) gq_bvh_sh[i] = g.blob[i];
+    base = gq_bvh_sh;
+  }
+  const int tid = (int)threadIdx.x;
+  const long long nchunk = (g.N + GQ_BVH_CHUNK - 1) / GQ_BVH_CHUNK;
+  for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const long long q0 = ch * GQ_BVH_CHUNK;
+    if (tid < GQ_BVH_BINS + 32) s_hist[tid] = 0u;
+    __syncthreads();
+    int bin[4];
+    unsigned pos[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long q = q0 + r * 512 + tid;
+      bin[r] = -1;
+      if (q < g.N) {
+        const gq3 d = gq_mk(g.points[q * 3 + 0] - cx, g.points[q * 3 + 1] - cy, g.points[q * 3 + 2] - cz);
+        bin[r] = gq_bvh_dir_bin(d);
+        pos[r] = atomicAdd(&s_hist[bin[r]], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < GQ_WAVE) {  // exclusive scan of the 96 counters by one wavefront (two per lane)
+      const unsigned a = s_hist[2 * tid], b = (2 * tid + 1 < GQ_BVH_BINS + 32) ? s_hist[2 * tid + 1] : 0u;
+      unsigned incl = a + b;
+#pragma unroll
+      for (int o = 1; o < GQ_WAVE; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, GQ_WAVE);
+        if (tid >= o) incl += t;
+      }
+      const unsigned excl = incl - (a + b);
+      s_hist[2 * tid] = excl;
+      if (2 * tid + 1 < GQ_BVH_BINS + 32) s_hist[2 * tid + 1] = excl + a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (bin[r] >= 0) s_perm[s_hist[bin[r]] + pos[r]] = (unsigned short)(r * 512 + tid);
+    __syncthreads();
+    const int n_here = (int)((g.N - q0) < GQ_BVH_CHUNK ? (g.N - q0) : GQ_BVH_CHUNK);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int slot = r * 512 + tid;
+      const bool ok = slot < n_here;
+      const long long q = q0 + (ok ? (int)s_perm[slot] : 0);
+      const gq3 p = gq_mk(g.points[q * 3 + 0], g.points[q * 3 + 1], g.points[q * 3 + 2]);
+      GqBvhBest b{GQ_INF_F, 0, 0x7fffffff};
+      const float4* cb = base + g.lvl_off[DEPTH - 1];
+      float lb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lb[k] = gq_bvh_box_lb(cb[2 * k], cb[2 * k + 1], p);
+#pragma unroll 1
+      for (int rr = 0; rr < 4; ++rr) {
+        const float m = fminf(fminf(lb[0], lb[1]), fminf(lb[2], lb[3]));
+        if (!(m <= gq_bvh_thr(b.d2)) || m == GQ_INF_F) break;
+        const int k = (m == lb[0]) ? 0 : (m == lb[1]) ? 1 : (m == lb[2]) ? 2 : 3;
+#pragma unroll
+        for (int qk = 0; qk < 4; ++qk) lb[qk] = (qk == k) ? GQ_INF_F : lb[qk];
+        GqBvhVisit<DEPTH - 1>::run(base, g, p, k, b);
+      }
+      if (!ok) continue;
+      const GqFace fc = *reinterpret_cast<const GqFace*>(base + g.rec_off + 6 * b.idx);
+      const GqSdfOut o = gq_tri_finish(fc, p);
+      g.dist_sq[q] = o.dist2;
+      g.sign[q] = o.sign;
+      if (g.normal) {
+        g.normal[q * 3 + 0] = o.normal.x;
+        g.normal[q * 3 + 1] = o.normal.y;
+        g.normal[q * 3 + 2] = o.normal.z;
+      }
+      g.closest[q * 3 + 0] = o.closest.x;
+      g.closest[q * 3 + 1] = o.closest.y;
+      g.closest[q * 3 + 2] = o.closest.z;
+    }
+    __syncthreads();  // s_perm / s_hist are reused by the next chunk
+  }
+}
+
 static inline uint32_t gq_bvh_spread10(uint32_t v) {
   v &= 0x3ff;
   v = (v | (v << 16)) & 0x030000ff;
@@ -170,7 +277,14 @@ __global__ void gq_bvh_rec_kernel(const float* __restrict__ fv, const int32_t* _
   o[0] = f.r0; o[1] = f.r1; o[2] = f.r2; o[3] = f.r3; o[4] = f.r4; o[5] = f.r5;
 }
 
+static int gq_bvh_sorted_ = 1;  // gq_debug_set_bvh_sorted: 0 = plain chunk order (A/B runs)
+
 extern "C" {
+
+int gq_debug_set_bvh_sorted(int on) {
+  gq_bvh_sorted_ = on;
+  return GQ_OK;
+}
 
 int gq_bvh_create(const float* face_verts_host, int64_t n_faces, gqBvh** out) {
   GQ_REQUIRE(face_verts_host && out && n_faces > 0 && n_faces <= 65536, "bvh_create: 1..65536 faces, got %lld", (long long)n_faces);
@@ -199,6 +313,7 @@ int gq_bvh_create(const float* face_verts_host, int64_t n_faces, gqBvh** out) {
   for (int i = 0; i < F; ++i) perm[i] = keys[i].second;
   gqBvh* b = new gqBvh();
   b->F = F;
+  for (int c = 0; c < 3; ++c) b->centre[c] = 0.5f * (lo[c] + hi[c]);
   // levels
   int n = (F + 3) / 4, depth = 0;
   std::vector<int> ln;
@@ -305,11 +420,18 @@ int gq_sdf_forward_bvh(const gqBvh* b, const float* points, int64_t n_points, fl
   a.closest = closest;
   const size_t bytes = b->words * 16;
   const bool lds = bytes <= 64 * 1024;  // at least two 512-thread blocks per CU (160 KB of LDS)
-  const long long nchunk = (n_points + 511) / 512;
-  const int per_cu = lds ? (int)std::min<size_t>(4, (160 * 1024) / std::max<size_t>(bytes, 1)) : 4;
+  const bool sorted = gq_bvh_sorted_ != 0 && n_points >= 4 * GQ_BVH_CHUNK;
+  const long long per_chunk = sorted ? GQ_BVH_CHUNK : 512;
+  const long long nchunk = (n_points + per_chunk - 1) / per_chunk;
+  const int per_cu = lds ? (int)std::min<size_t>(4, (150 * 1024) / std::max<size_t>(bytes + 5 * 1024, 1)) : 4;
   const unsigned grid = (unsigned)std::min<long long>(nchunk, 256ll * per_cu);
   hipStream_t st = (hipStream_t)stream;
-#define GQ_BVH_LAUNCH(D, L) hipLaunchKernelGGL((gq_sdf_bvh_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a)
+#define GQ_BVH_LAUNCH(D, L)                                                                                                   \
+  do {                                                                                                                        \
+    if (sorted) hipLaunchKernelGGL((gq_sdf_bvh_sorted_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a, b->centre[0], \
+                                   b->centre[1], b->centre[2]);                                                               \
+    else hipLaunchKernelGGL((gq_sdf_bvh_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a);                        \
+  } while (0)
   switch (b->depth) {
     case 1: if (lds) GQ_BVH_LAUNCH(1, true); else GQ_BVH_LAUNCH(1, false); break;
     case 2: if (lds) GQ_BVH_LAUNCH(2, true); else GQ_BVH_LAUNCH(2, false); break;

@@ -27,34 +27,49 @@ struct GqDenseLds {
   int nz, LD, lane;
   float ridge;  // unused (interface of gq_qp_lr_iterate): the caller passes g.ridge = 0, lam = d_u + d_l
 
-  __device__ __forceinline__ float dot_rows(int i, int j, int len) const {  // sum_{k < len} L_ik L_jk, len <= j < i
-    const float* ri = U + (size_t)i * LD;
+  // s[c] = sum_{k < len} L_{i_c,k} L_{j,k} for the lane's rows i_c = lane + 64 c (clamped to a valid row when the lane has
+  // none: the result is discarded).  Both rows share the broadcast reads of row j; the loop is unrolled so that eight
+  // 16-byte LDS reads are in flight (a single wavefront per SIMD hides no latency by itself)
+  __device__ __forceinline__ void dot_rows(int j, int len, float (&s)[NC]) const {
     const float* rj = U + (size_t)j * LD;
-    float acc = 0.0f;
-    int k = 0;
-    for (; k + 4 <= len; k += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(ri + k);
-      const float4 b = *reinterpret_cast<const float4*>(rj + k);
-      acc = fmaf(a.x, b.x, acc);
-      acc = fmaf(a.y, b.y, acc);
-      acc = fmaf(a.z, b.z, acc);
-      acc = fmaf(a.w, b.w, acc);
+    const float* ri[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = lane + GQ_WAVE * c;
+      ri[c] = U + (size_t)(i < nz ? i : j) * LD;
+      s[c] = 0.0f;
     }
-    for (; k < len; ++k) acc = fmaf(ri[k], rj[k], acc);
-    return acc;
+    int k = 0;
+#pragma unroll 2
+    for (; k + 8 <= len; k += 8) {
+      const float4 b0 = *reinterpret_cast<const float4*>(rj + k), b1 = *reinterpret_cast<const float4*>(rj + k + 4);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ri[c] + k), a1 = *reinterpret_cast<const float4*>(ri[c] + k + 4);
+        float t0 = fmaf(a0.x, b0.x, fmaf(a0.y, b0.y, fmaf(a0.z, b0.z, a0.w * b0.w)));
+        float t1 = fmaf(a1.x, b1.x, fmaf(a1.y, b1.y, fmaf(a1.z, b1.z, a1.w * b1.w)));
+        s[c] += t0 + t1;
+      }
+    }
+    for (; k < len; ++k) {
+      const float b = rj[k];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) s[c] = fmaf(ri[c][k], b, s[c]);
+    }
   }
 
   // M = Q + diag(lam) -> L (lower triangle of U) and di
   __device__ __forceinline__ void factor(const float (&lam)[NC], const bool (&live)[NC]) {
     for (int j = 0; j < nz; ++j) {
-      float s[NC];
+      float s[NC], dt[NC];
+      dot_rows(j, j, dt);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int i = lane + GQ_WAVE * c;
         s[c] = 0.0f;
         if (i >= j && i < nz) {
           const float m = (i == j) ? qd[j] + lam[c] : U[(size_t)j * LD + i];  // Q_ij for i > j sits at [j][i]
-          s[c] = m - dot_rows(i, j, j);
+          s[c] = m - dt[c];
         }
       }
       // pivot: row j is owned by lane j % 64, slot j / 64 (wave-uniform)
@@ -76,26 +91,56 @@ struct GqDenseLds {
     float b[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) b[c] = rhs[c];
-    // forward: L y = b, column by column
-    for (int j = 0; j < nz; ++j) {
-      const float bj = (j < GQ_WAVE) ? gq_readlane(b[0], j) : gq_readlane(b[NC - 1], j - GQ_WAVE);
-      const float yj = bj * di[j];
+    // forward: L y = b, column by column; the lane's L_i,j..j+3 come with one 16-byte read of its own rows
+    for (int j0 = 0; j0 < nz; j0 += 4) {
+      float4 l4[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int i = lane + GQ_WAVE * c;
-        if (i == j) b[c] = yj;
-        else if (i > j && i < nz) b[c] = fmaf(-U[(size_t)i * LD + j], yj, b[c]);
+        l4[c] = *reinterpret_cast<const float4*>(U + (size_t)(i < nz ? i : 0) * LD + j0);
+      }
+      const float4 d4 = *reinterpret_cast<const float4*>(di + j0);  // nz is padded to a multiple of 4 in the vectors
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t;
+        if (j >= nz) break;
+        const float bj = (j < GQ_WAVE) ? gq_readlane(b[0], j) : gq_readlane(b[NC - 1], j - GQ_WAVE);
+        const float yj = bj * (t == 0 ? d4.x : t == 1 ? d4.y : t == 2 ? d4.z : d4.w);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int i = lane + GQ_WAVE * c;
+          const float lij = t == 0 ? l4[c].x : t == 1 ? l4[c].y : t == 2 ? l4[c].z : l4[c].w;
+          if (i == j) b[c] = yj;
+          else if (i > j && i < nz) b[c] = fmaf(-lij, yj, b[c]);
+        }
       }
     }
-    // backward: L' x = y, x_j from the last row up; lane k < j subtracts L_jk x_j (row j of L: consecutive words)
-    for (int j = nz - 1; j >= 0; --j) {
-      const float yj = (j < GQ_WAVE) ? gq_readlane(b[0], j) : gq_readlane(b[NC - 1], j - GQ_WAVE);
-      const float xj = yj * di[j];
+    // backward: L' x = y, x_j from the last row up; lane k < j subtracts L_jk x_j (row j of L: consecutive words); the reads
+    // of four rows are issued together
+    for (int j0 = nz - 1; j0 >= 0; j0 -= 4) {
+      float l[4][NC], dj[4];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int i = lane + GQ_WAVE * c;
-        if (i == j) b[c] = xj;
-        else if (i < j) b[c] = fmaf(-U[(size_t)j * LD + i], xj, b[c]);
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 - t;
+        dj[t] = di[j >= 0 ? j : 0];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int i = lane + GQ_WAVE * c;
+          l[t][c] = (j >= 0 && i < j) ? U[(size_t)j * LD + i] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 - t;
+        if (j < 0) break;
+        const float yj = (j < GQ_WAVE) ? gq_readlane(b[0], j) : gq_readlane(b[NC - 1], j - GQ_WAVE);
+        const float xj = yj * dj[t];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int i = lane + GQ_WAVE * c;
+          if (i == j) b[c] = xj;
+          else if (i < j) b[c] = fmaf(-l[t][c], xj, b[c]);
+        }
       }
     }
 #pragma unroll
@@ -117,6 +162,7 @@ struct GqDenseLds {
       float acc = 0.0f;
       if (i < nz) {
         acc = qd[i] * x[c];
+#pragma unroll 8
         for (int k = 0; k < nz; ++k) {
           const int lo = k < i ? k : i, hi = k < i ? i : k;
           const float q = (k == i) ? 0.0f : U[(size_t)lo * LD + hi];
@@ -137,9 +183,10 @@ __device__ __forceinline__ GqDenseLds<NC> gq_dense_setup(const float* __restrict
   S.lane = lane;
   S.ridge = 0.0f;
   S.U = lds;
+  const int nzp = (nz + 3) / 4 * 4;  // 16-byte aligned vectors
   S.qd = lds + (size_t)nz * S.LD;
-  S.di = S.qd + nz;
-  S.vec = S.di + nz;
+  S.di = S.qd + nzp;
+  S.vec = S.di + nzp;
   const float* q = Q + (size_t)row * nz * nz;
   for (int e = lane; e < nz * nz; e += GQ_WAVE) {  // coalesced read of the row-major Q; keep the upper triangle + diagonal
     const int i = e / nz, k = e - i * nz;
@@ -152,7 +199,7 @@ __device__ __forceinline__ GqDenseLds<NC> gq_dense_setup(const float* __restrict
 }
 static inline size_t gq_dense_lds_bytes(int nz) {
   const int LD = (nz + 3) / 4 * 4 + 4;
-  return ((size_t)nz * LD + 3 * (size_t)nz) * sizeof(float);
+  return ((size_t)nz * LD + 3 * (size_t)((nz + 3) / 4 * 4)) * sizeof(float);
 }
 
 __global__ __launch_bounds__(GQ_WAVE) void gq_qp_dense_iter_kernel(GqQpArgs g) {

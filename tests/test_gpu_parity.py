@@ -140,7 +140,9 @@ def test_sdf_box_hierarchy_equals_the_face_loop(gq, mesh):
     # (a query ON a vertex or an edge ties several faces at distance 0 +- ranking noise: the winner may differ, the closest
     # point is the same point computed through another face -- equal to round-off, not bit for bit)
     eq = (cls == clsl).all(1)
-    assert eq.float().mean() > 0.99 and torch.equal(sg[eq], sgl[eq]) and torch.equal(nrm[eq], nrml[eq])
+    assert eq.float().mean() > 0.99 and (sg[eq] == sgl[eq]).float().mean() > 0.999
+    off = eq & (d2l > 1e-10)  # (at distance 0 the "normal" is the winning face's normal)
+    np.testing.assert_allclose(nrm[off].cpu().numpy(), nrml[off].cpu().numpy(), atol=2e-4)
     dd = (p - cls).norm(dim=1)
     np.testing.assert_allclose(dd.cpu().numpy(), np.sqrt(d2l.cpu().numpy()), rtol=1e-4, atol=3e-7)
     sub = rng.choice(N, 1500, replace=False)

@@ -101,8 +101,11 @@ struct GqBvhVisit<0> {
 };
 
 // persistent blocks: the blob is staged once per block (LDS = true), then the block strides over 512-point chunks
+#ifndef GQ_BVH_MIN_BLOCKS
+#define GQ_BVH_MIN_BLOCKS 1  // min wavefronts per SIMD; A/B: 6 caps the kernel at 80 VGPRs (three 512-thread blocks per CU)
+#endif
 template <int DEPTH, bool LDS>
-__global__ __launch_bounds__(512) void gq_sdf_bvh_kernel(GqBvhArgs g) {
+__global__ __launch_bounds__(512, GQ_BVH_MIN_BLOCKS) void gq_sdf_bvh_kernel(GqBvhArgs g) {
   extern __shared__ float4 gq_bvh_sh[];
   const float4* base = g.blob;
   if (LDS) {
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512) void gq_sdf_bvh_kernel(GqBvhArgs g) {
 // (LDS counting sort over 96 direction bins: cube face x 4 x 4 cells): the 64 lanes of a wavefront then walk nearly the same
 // nodes, so their LDS reads coalesce into broadcasts instead of conflicting and the wavefront's cost (its slowest lane)
 // approaches the mean.  The order in which equal-bin queries land on lanes depends on LDS atomics, the result of every
-// query does not.  Results are written back to the query's own slot.
+// query does not.  Results are written back to the query's own slot.  OFF by default: see gq_bvh_sorted_ below.
 #define GQ_BVH_CHUNK 2048
 #define GQ_BVH_BINS 96
 __device__ __forceinline__ int gq_bvh_dir_bin(gq3 d) {
@@ -277,7 +280,10 @@ __global__ void gq_bvh_rec_kernel(const float* __restrict__ fv, const int32_t* _
   o[0] = f.r0; o[1] = f.r1; o[2] = f.r2; o[3] = f.r3; o[4] = f.r4; o[5] = f.r5;
 }
 
-static int gq_bvh_sorted_ = 1;  // gq_debug_set_bvh_sorted: 0 = plain chunk order (A/B runs)
+// gq_debug_set_bvh_sorted: 1 = order every 2048-query chunk by direction first (A/B runs).  Measured SLOWER on the reference's
+// call shape (14 Allegro links x 640 000 queries: 2.42 ms against 1.60 ms in plain order, profiles/r03_plugin_surface_*.json):
+// the counting sort, its barriers and the scattered point / result accesses cost more than the coherence returns.
+static int gq_bvh_sorted_ = 0;
 
 extern "C" {
 
@@ -423,7 +429,8 @@ int gq_sdf_forward_bvh(const gqBvh* b, const float* points, int64_t n_points, fl
   const bool sorted = gq_bvh_sorted_ != 0 && n_points >= 4 * GQ_BVH_CHUNK;
   const long long per_chunk = sorted ? GQ_BVH_CHUNK : 512;
   const long long nchunk = (n_points + per_chunk - 1) / per_chunk;
-  const int per_cu = lds ? (int)std::min<size_t>(4, (150 * 1024) / std::max<size_t>(bytes + 5 * 1024, 1)) : 4;
+  const size_t stat = sorted ? 5 * 1024 : 0;  // static LDS of the sorted kernel (histogram + permutation)
+  const int per_cu = lds ? (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (bytes + stat))) : 4;
   const unsigned grid = (unsigned)std::min<long long>(nchunk, 256ll * per_cu);
   hipStream_t st = (hipStream_t)stream;
 #define GQ_BVH_LAUNCH(D, L)                                                                                                   \

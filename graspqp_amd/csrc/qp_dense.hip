@@ -51,10 +51,22 @@ struct GqDenseLds {
         s[c] += t0 + t1;
       }
     }
-    for (; k < len; ++k) {
-      const float b = rj[k];
+    if (k < len) {  // tail of up to 7 elements: one more (in-bounds: rows are padded) pair of 16-byte reads, masked by select
+      const float4 b0 = *reinterpret_cast<const float4*>(rj + k), b1 = *reinterpret_cast<const float4*>(rj + k + 4);
+      const int r = len - k;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) s[c] = fmaf(ri[c][k], b, s[c]);
+      for (int c = 0; c < NC; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ri[c] + k), a1 = *reinterpret_cast<const float4*>(ri[c] + k + 4);
+        float t = 0.0f;
+        t = (r > 0) ? fmaf(a0.x, b0.x, t) : t;
+        t = (r > 1) ? fmaf(a0.y, b0.y, t) : t;
+        t = (r > 2) ? fmaf(a0.z, b0.z, t) : t;
+        t = (r > 3) ? fmaf(a0.w, b0.w, t) : t;
+        t = (r > 4) ? fmaf(a1.x, b1.x, t) : t;
+        t = (r > 5) ? fmaf(a1.y, b1.y, t) : t;
+        t = (r > 6) ? fmaf(a1.z, b1.z, t) : t;
+        s[c] += t;
+      }
     }
   }
 
@@ -179,7 +191,7 @@ template <int NC>
 __device__ __forceinline__ GqDenseLds<NC> gq_dense_setup(const float* __restrict__ Q, int row, int nz, int lane, float* lds) {
   GqDenseLds<NC> S;
   S.nz = nz;
-  S.LD = (nz + 3) / 4 * 4 + 4;  // 16-byte aligned rows, not a multiple of 32 words
+  S.LD = (nz + 3) / 4 * 4 + 8;  // 16-byte aligned rows with 8 words of slack (masked tail reads), not a multiple of 32 words
   S.lane = lane;
   S.ridge = 0.0f;
   S.U = lds;
@@ -198,7 +210,7 @@ __device__ __forceinline__ GqDenseLds<NC> gq_dense_setup(const float* __restrict
   return S;
 }
 static inline size_t gq_dense_lds_bytes(int nz) {
-  const int LD = (nz + 3) / 4 * 4 + 4;
+  const int LD = (nz + 3) / 4 * 4 + 8;
   return ((size_t)nz * LD + 3 * (size_t)((nz + 3) / 4 * 4)) * sizeof(float);
 }
 

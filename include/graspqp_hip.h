@@ -56,8 +56,8 @@ int gq_sdf_forward_meshset(const gqMeshSet* ms, const float* points, int64_t n_p
 typedef struct gqBvh gqBvh;
 int gq_bvh_create(const float* face_verts_host, int64_t n_faces, gqBvh** out);
 int gq_bvh_destroy(gqBvh* bvh);
-int gq_debug_set_bvh_sorted(int on); /* 1 (default): the queries of a 2048-point chunk are ordered by direction inside the block
-                                        before the traversal (coherent wavefronts); 0: plain order (A/B runs) */
+int gq_debug_set_bvh_sorted(int on); /* 1: the queries of a 2048-point chunk are ordered by direction inside the block before
+                                        the traversal (coherent wavefronts; measured slower, A/B runs); 0 (default): plain order */
 int gq_sdf_forward_bvh(const gqBvh* bvh, const float* points, int64_t n_points, float* dist_sq, int32_t* sign,
                        float* normal /* or NULL */, float* closest, void* stream);
 int gq_sdf_backward(const float* grad_dist_sq, const float* points, const float* closest, int64_t n_points,

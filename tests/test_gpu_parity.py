@@ -132,8 +132,8 @@ def test_sdf_box_hierarchy_equals_the_face_loop(gq, mesh):
     assert (id(f), "bvh") in gq.ops._MESH_CACHE
     d2l, sgl, nrml, clsl = torch.ops.graspqp_amd.compute_sdf(p, f)  # the face loop on the raw tensors
     torch.cuda.synchronize()
-    same = (d2 == d2l)
-    assert same.float().mean() > 0.9995, float(same.float().mean())
+    same = (d2 == d2l)  # (queries ON a vertex tie several faces at distance ~0: another winner, a distance of 0 vs 1e-17)
+    assert same.float().mean() > 0.99, float(same.float().mean())
     np.testing.assert_allclose(d2.cpu().numpy(), d2l.cpu().numpy(), rtol=2e-5, atol=1e-10)
     # where the same face won, everything is bit-identical; elsewhere (faces tied within the ranking noise) the closest
     # point may jump to the other face, but it is as close
@@ -148,6 +148,14 @@ def test_sdf_box_hierarchy_equals_the_face_loop(gq, mesh):
     sub = rng.choice(N, 1500, replace=False)
     od2, osg, _, _ = osdf.compute_sdf(torch.tensor(pts[sub], dtype=torch.float64), torch.tensor(fv, dtype=torch.float64))
     np.testing.assert_allclose(np.sqrt(d2.cpu().numpy()[sub]), np.sqrt(od2.numpy()), rtol=1e-4, atol=2e-7)
+    # the direction-sorted variant of the kernel (A/B switch): same answers, query for query
+    gq.C.call("gq_debug_set_bvh_sorted", 1)
+    try:
+        d2s, sgs, _, clss = gq.ops.compute_sdf(p, f)
+        torch.cuda.synchronize()
+    finally:
+        gq.C.call("gq_debug_set_bvh_sorted", 0)
+    assert torch.equal(d2s, d2) and torch.equal(sgs, sg) and torch.equal(clss, cls)
     # gradient route (only dist_sq w.r.t. points)
     pg = p[:40000].clone().requires_grad_()
     d2g, _, _, clg = gq.ops.compute_sdf(pg, f)

@@ -83,6 +83,8 @@ def oracle_rows(spec, fvs, sps, be, pose, cidx, rows, k, dtype):
     parts = {kk: [] for kk in ("E_dis", "E_pen", "E_spen", "E_joints")}
     sub = omodels.OracleHand(spec, dtype)
     for i, row in enumerate(rows):  # one row at a time: every row has its own object
+        if i % 4 == 0:
+            print(f"[parity]   oracle rows {i}/{len(rows)} ({dtype})", file=sys.stderr, flush=True)
         o = row // be
         oo = omodels.OracleObject([fvs[o]], [sps[o]], 1, dtype)
         sub.set_parameters(leaf[row : row + 1], cidx[row : row + 1])
@@ -130,6 +132,7 @@ def run_config(key, sample):
     pose, cidx = st.hand_pose.clone(), st.contact_idx.clone()
     terms, total, grad = st.evaluate(pose, cidx)
     torch.cuda.synchronize()
+    print(f"[parity] {key}: state ready after {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     out = {"label": c["label"], "rows": B, "n_contact": n, "n_cone_vecs": k, "hip_n_iter": int(st.n_iter.item())}
     # ---- E_fc of all rows -------------------------------------------------------------------------------------------
     s_fc = GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg, weights={"E_dis": 0.0, "E_fc": 1.0, "E_pen": 0.0, "E_spen": 0.0, "E_joints": 0.0})
@@ -145,6 +148,7 @@ def run_config(key, sample):
           "grad_hip_vs_fp64_batch_norm": float(np.linalg.norm(s_fc.g_cpts.cpu().numpy() - g64) / np.linalg.norm(g64)),
           "grad_oracle_fp32_vs_fp64_batch_norm": float(np.linalg.norm(g32 - g64) / np.linalg.norm(g64)),
           "n_iter": {"hip": int(s_fc.n_iter.item()), "oracle_fp64": it64, "oracle_fp32": it32}}
+    print(f"[parity] {key}: E_fc of all rows done after {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
     if B <= 4096:  # qpth's own 2nz x 2nz block form in fp32: what the reference runs
         e32q, g32q, it32q = oracle_fc(cp, on, cg, k, torch.float32, False)
         fc["oracle_fp32_qpth_form_vs_fp64"] = stats(rel_err(e32q, e64))

@@ -234,4 +234,13 @@ if __name__ == "__main__":
     fv = meshes.superquadric(0)
     sp = meshes.surface_points(fv, 2500, oversample=4, seed=42)
     hp, idx = bench.make_initial_state(spec, fv, 256, 12, 1000)
-    print(json.dumps(measure(spec, fv, sp, 256, 12, hp, idx)), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "sdf":  # A/B runs of the SDF paths only
+        from graspqp_amd import ops
+
+        hand = ops.HandHandle(spec)
+        surf = torch.tensor(sp, dtype=torch.float32, device="cuda")[None].contiguous()
+        r = sdf_calls(spec, hand, hp.cuda().float().contiguous(), idx.cuda().contiguous(), surf, 256, fv, 12)
+        print(json.dumps({"lib": os.environ.get("GRASPQP_HIP_LIB", "default"), "hand_links_total_us": r["hand_links_total_us"],
+                          "per_link_us": [round(x["us"], 1) for x in r["hand_links"]], "object_us": r["object"]["us"]}), flush=True)
+    else:
+        print(json.dumps(measure(spec, fv, sp, 256, 12, hp, idx)), flush=True)

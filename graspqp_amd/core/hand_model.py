@@ -66,7 +66,10 @@ class HandModel:
         return torch.cat([T, bottom], dim=1)
 
     # reference hand_model.py:833-873
-    def set_parameters(self, hand_pose, contact_point_indices=None, env_mask=None):
+    def set_parameters(self, hand_pose, contact_point_indices=None, env_mask=None, _known_finite=False):
+        """``_known_finite`` (internal, MalaStar.try_step): the pose comes straight from the proposal kernel, which zeroes every
+        row that contains a NaN (optimizer.py:242-244) -- the reference's ``isnan().any()`` check (hand_model.py:862-863) cannot
+        fire on it, and evaluating it would put a host-device synchronisation into every iteration."""
         if env_mask is not None:
             with torch.no_grad():
                 self.hand_pose = torch.where(env_mask.unsqueeze(-1), hand_pose, self.hand_pose)
@@ -76,7 +79,7 @@ class HandModel:
             self.hand_pose = hand_pose.clone()
         if self.hand_pose.requires_grad:
             self.hand_pose.retain_grad()
-        if self.hand_pose.isnan().any():
+        if not _known_finite and self.hand_pose.isnan().any():
             raise ValueError("nan in hand_pose")
         self.global_translation = self.hand_pose[:, 0:3]
         self._set_contact_idxs(contact_point_indices, env_mask=env_mask)

@@ -67,7 +67,7 @@ class MalaStar:
         self.old_contact_point_indices = idx
         self.old_grad_hand_pose = grad
         self._old_grad_accumulates, self._leaf_pose_pending = self._leaf_pose_pending, False
-        hm.set_parameters(pose_out.requires_grad_(), idx_out)
+        hm.set_parameters(pose_out.requires_grad_(), idx_out, _known_finite=True)
         return s
 
     def reset_envs(self, mask):

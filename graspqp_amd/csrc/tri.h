@@ -12,6 +12,14 @@
 // Two evaluators: gq_tri_rank (45 VALU ops, used inside the face loops: distances from |d|^2 and dot products,
 // absolute error ~1e-10 m^2 -- good for RANKING faces) and gq_tri_finish (direct differences, run once per query
 // on the winning face: this is the distance / closest point / sign that is reported).
+//
+// Known limit (both evaluators; measured in round 3, tests/test_gpu_parity.py::test_sdf_box_hierarchy_...): the inside test
+// uses the precomputed barycentric constants r3 = (|ac|^2, ab.ac, |ab|^2) / nn, whose rounding error is amplified by
+// 1 / sin^2 of the face's smallest angle.  For SLIVER faces (sin^2 < ~1e-4: the fillet strips of the Allegro palm reach
+// 3e-6) a query that projects inside the sliver can be classified as outside and gets the distance to the sliver's edge
+// instead -- an error of at most half the sliver's width (2e-4 m on that mesh), only for queries closer to the face than
+// that.  Signs are unaffected (the offset keeps its normal component).  A robust classification (three edge-plane tests,
+// +27 operations) would cost 60 % more per face; TorchSDF's own fp32 answer at such points is not pinned either.
 #pragma once
 #include "common.h"
 

@@ -126,6 +126,12 @@ def test_sdf_box_hierarchy_equals_the_face_loop(gq, mesh):
         fv.reshape(-1, 3)[rng.integers(0, fv.shape[0] * 3, 5000)],                 # exactly on vertices
         fv.mean(1)[rng.integers(0, fv.shape[0], 5001)] + rng.normal(size=(5001, 3)) * 1e-4,  # a hair off face centres
     ]).astype(np.float32)
+    # sliver faces (fillet strips; sin^2 of the smallest angle down to 3e-6 on the Allegro palm): the fp32 inside test of tri.h
+    # can place a query that projects INTO a sliver outside it -> distance to the sliver's edge, at most half its width off
+    e = np.stack([fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 1], fv[:, 0] - fv[:, 2]], 1).astype(np.float64)
+    area2 = np.linalg.norm(np.cross(e[:, 0], -e[:, 2]), axis=1)
+    sliver = area2 / (np.linalg.norm(e, axis=2).max(1) ** 2) < 3e-2  # height / longest edge
+    half_width = float((area2 / np.linalg.norm(e, axis=2).max(1))[sliver].max() / 2) if sliver.any() else 0.0
     assert pts.shape[0] == N
     p, f = torch.tensor(pts, device="cuda"), torch.tensor(fv, device="cuda")
     d2, sg, nrm, cls = gq.ops.compute_sdf(p, f)
@@ -147,7 +153,9 @@ def test_sdf_box_hierarchy_equals_the_face_loop(gq, mesh):
     np.testing.assert_allclose(dd.cpu().numpy(), np.sqrt(d2l.cpu().numpy()), rtol=1e-4, atol=3e-7)
     sub = rng.choice(N, 1500, replace=False)
     od2, osg, _, _ = osdf.compute_sdf(torch.tensor(pts[sub], dtype=torch.float64), torch.tensor(fv, dtype=torch.float64))
-    np.testing.assert_allclose(np.sqrt(d2.cpu().numpy()[sub]), np.sqrt(od2.numpy()), rtol=1e-4, atol=2e-7)
+    np.testing.assert_allclose(np.sqrt(d2.cpu().numpy()[sub]), np.sqrt(od2.numpy()), rtol=1e-4, atol=2e-7 + half_width)
+    tight = np.abs(np.sqrt(d2.cpu().numpy()[sub]) - np.sqrt(od2.numpy())) <= 1e-4 * np.sqrt(od2.numpy()) + 2e-7
+    assert tight.mean() > 0.98, tight.mean()  # ... and only the few queries inside a sliver's width use that allowance
     # the direction-sorted variant of the kernel (A/B switch): same answers, query for query
     gq.C.call("gq_debug_set_bvh_sorted", 1)
     try:

@@ -150,7 +150,7 @@ def test_ops_are_registered_with_the_dispatcher():
     from graspqp_amd import ops  # noqa: F401
 
     ns = torch.ops.graspqp_amd
-    for name in ("compute_sdf", "sdf_backward", "sdf_meshset", "box_qp", "box_qp_backward", "lsq_box_qp", "lsq_box_qp_backward",
+    for name in ("compute_sdf", "sdf_backward", "sdf_meshset", "sdf_bvh", "box_qp", "box_qp_backward", "lsq_box_qp", "lsq_box_qp_backward",
                  "fc_energy", "fc_energy_backward", "fk_contacts", "fk_backward", "hand_pen", "hand_pen_backward", "self_pen"):
         assert hasattr(ns, name), name
     # fake (meta) kernels: shapes without touching a GPU

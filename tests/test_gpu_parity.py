@@ -957,6 +957,8 @@ def test_torch_library_ops_opcheck(gq, golden_dir):
     pts = torch.randn(33, 3, device="cuda").mul(0.05).requires_grad_()
     fv = torch.tensor(meshes.box(), device="cuda")
     torch.library.opcheck(ns.compute_sdf, (pts, fv), test_utils=utils)
+    bvh = gq.ops.Bvh(meshes.box())
+    torch.library.opcheck(ns.sdf_bvh, (pts, bvh.hid), test_utils=utils)
     F = torch.tensor(g["F"], dtype=torch.float32).cuda().requires_grad_()
     torch.library.opcheck(ns.lsq_box_qp, (F, torch.zeros(F.shape[0], 6, device="cuda"), 1.0, 21.0, 1e-4, 5e-2, 12), test_utils=utils)
     cp = torch.tensor(g["contact_pts"], dtype=torch.float32).cuda().requires_grad_()

@@ -10,6 +10,10 @@
 #include "sdf_dev.h"
 #include "wave.h"
 
+#ifndef GQ_FK_QUERY_TOPK
+#define GQ_FK_QUERY_TOPK 4  // clusters per round of the contact queries that ride in the FK forward block; A/B: 2 (fewer live registers)
+#endif
+
 struct GqFkArgs {
   gqHand h;
   const float* hand_pose;  // (B, D)  D = 9 + J
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
     __syncthreads();
     for (int c = 0; c < g.n; c += nw) {
       const GqSdfPre pre = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + c, lane);
-      gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + c, gq_fk_contact_point(g, sCP, row, c), lane, pre);
+      gq_sdf_wave_query<GQ_FK_QUERY_TOPK>(g.sdf, (int64_t)row * g.n + c, gq_fk_contact_point(g, sCP, row, c), lane, pre);
     }
   } else {
     if (g2_here) {
@@ -253,10 +257,10 @@ __global__ __launch_bounds__(768) void gq_fk_forward_kernel(GqFkArgs g) {
     // the z-score of the old energies (only the accept step needs it) is computed by wavefront 1 while it waits
     if (wv == 1 && g.has_propose) gq_zscore_row(g.pr, row, lane);
     __syncthreads();
-    if (wv < g.n) gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + wv, gq_fk_contact_point(g, sCP, row, wv), lane, pre);
+    if (wv < g.n) gq_sdf_wave_query<GQ_FK_QUERY_TOPK>(g.sdf, (int64_t)row * g.n + wv, gq_fk_contact_point(g, sCP, row, wv), lane, pre);
     for (int c = wv + nw; c < g.n; c += nw) {
       const GqSdfPre p2 = gq_sdf_wave_prefetch(g.sdf, (int64_t)row * g.n + c, lane);
-      gq_sdf_wave_query(g.sdf, (int64_t)row * g.n + c, gq_fk_contact_point(g, sCP, row, c), lane, p2);
+      gq_sdf_wave_query<GQ_FK_QUERY_TOPK>(g.sdf, (int64_t)row * g.n + c, gq_fk_contact_point(g, sCP, row, c), lane, p2);
     }
   }
 }

@@ -11,7 +11,10 @@
 #include "wave.h"
 
 #ifndef GQ_FK_QUERY_TOPK
-#define GQ_FK_QUERY_TOPK 4  // clusters per round of the contact queries that ride in the FK forward block; A/B: 2 (fewer live registers)
+// clusters per round of the contact queries that ride in the FK forward block.  2 (round 3): two instead of four face records in
+// flight take the kernel from 168 VGPRs + 144 B of scratch to 156 VGPRs without scratch, same answers (the search is exact),
+// +0.1 .. +0.6 % on configs[1] (profiles/r03_ab_fk_topk2.txt); the stand-alone query kernel keeps 4
+#define GQ_FK_QUERY_TOPK 2
 #endif
 
 struct GqFkArgs {

@@ -24,8 +24,8 @@ BUDGET = {  # kernel -> (max VGPRs, max scratch bytes per lane)
     "gq_fk_backward_kernel": (128, 0),
     "gq_fk_forward_row_kernel": (128, 0),       # kinematics without contact queries (large batches): nothing spills
     "gq_fc_tail_kernel<1, 0>": (128, 16),
-    "gq_fk_forward_kernel": (170, 160),         # 12 wavefronts per block: 170 is the hardware limit; known spill of
-                                                # 38 words around the contact query (once per query, not in its loops)
+    "gq_fk_forward_kernel": (160, 0),           # 12 wavefronts per block (hardware limit 170); since round 3 two records in
+                                                # flight per query round: 156 VGPRs, nothing spills
     "gq_stage_b_kernel<1, 4>": (168, 0),
     "gq_hand_pen_bwd_kernel<10>": (128, 0),     # <= 2560 surface points: ten slices per round, 4 wavefronts per SIMD
     "gq_stage_alt_kernel<1, 2>": (128, 0),      # dexgrasp role + penetration query
@@ -45,6 +45,6 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert r["vgpr"] + r["agpr"] <= vmax, (name, r)
         assert r["scratch"] <= smax, (name, r)
     spilled = {k: v["scratch"] for k, v in res.items() if v["scratch"] > 0}
-    assert set(spilled) <= {"gq_fk_forward_kernel", "gq_sdf_wave_kernel<4>", "gq_fc_head_stop_kernel<1>",
+    assert set(spilled) <= {"gq_sdf_wave_kernel<4>", "gq_fc_head_stop_kernel<1>",
                             "gq_stage_a_kernel<1, true, 2>", "gq_stage_a_kernel<1, true, 1>", "gq_fc_tail_kernel<1, 0>",
                             "gq_stage_alt_kernel<2, 2>", "gq_stage_alt_kernel<2, 1>"}, f"new register spills: {spilled}"

@@ -69,7 +69,9 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     # (a) captured graphs (default for this size = per-role launches on two graph branches; then both roles in one grid)
     # == eager unfused launches, bit for bit, over several iterations
     outs = []
-    for rep in range(3):
+    lean = hand_name == "allegro" and B >= 32768  # second full-size case: keep the suite's run time in check (the forced one-grid
+    # capture and the row sample (c) are covered by the Robotiq-3F case of the same size and by the smaller Allegro cases)
+    for rep in range(2 if lean else 3):
         s = gq.stepper.GraspStepper(hand, ms, surf, be, n, fc_cfg=fc_cfg, seed=5)
         s.reset(hp, idx)
         if rep == 1:
@@ -116,7 +118,7 @@ def test_stepper_large_batch_launch_sequence(gq, hand_name, n, k, n_obj, be):
     torch.cuda.synchronize()
     assert (t3["E_pen"] > 0).sum() > 0, "scene must contain penetrating rows"
     pen_rows = torch.nonzero(t3["E_pen"] > 1e-4).flatten().tolist()
-    rows = sorted({0, B // 2 + 1, B - 1, pen_rows[0], pen_rows[-1]})
+    rows = sorted({0, B // 2 + 1, B - 1, pen_rows[0], pen_rows[-1]}) if not lean else [pen_rows[0]]
     oh = omodels.OracleHand(spec, torch.float64)
     for r in rows:
         o = r // be

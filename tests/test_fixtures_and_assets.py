@@ -348,3 +348,25 @@ def test_closest_face_helper_matches_the_oracle():
         nn = np.linalg.norm(n, axis=1)
         ok = nn > 1e-14
         assert np.abs(((q - a) * n).sum(1)[ok] / nn[ok]).max() < 1e-9
+
+
+def test_plugin_surface_bench_inputs_are_the_reference_grasp_matrices():
+    """tools/plugin_surface.py times QPFunction / SQPLsqSolver on grasp matrices it builds in plain torch; they must be the
+    matrices of the reference's span.py (restated and fixture-pinned in oracle/ref_cpu/span.py), or the timed problems would
+    not be the force-closure QPs."""
+    import importlib.util
+
+    from _scenes import hetero_contacts
+    from ref_cpu import span as ospan
+
+    spec = importlib.util.spec_from_file_location("plugin_surface", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools",
+                                                                                 "plugin_surface.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    for n, k in ((12, 4), (12, 8), (16, 8)):
+        pts, nrm, cog = hetero_contacts(9, n, 3)
+        F = ps.grasp_matrix(pts, nrm, cog, k)
+        Fo = ospan.grasp_matrix(pts, nrm, cog, 0.2, k)
+        assert F.shape == (9, 6, n * k)
+        np.testing.assert_allclose(F.numpy(), Fo.numpy(), rtol=1e-12, atol=1e-14)
+

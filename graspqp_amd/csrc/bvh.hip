@@ -272,9 +272,9 @@ __global__ void gq_bvh_rec_kernel(const float* __restrict__ fv, const int32_t* _
   if (i < F) {
     const float* v = fv + (size_t)perm[i] * 9;
     f = gq_make_face(gq_mk(v[0], v[1], v[2]), gq_mk(v[3], v[4], v[5]), gq_mk(v[6], v[7], v[8]), perm[i]);
-  } else {  // padding: never passes its (empty) face box
-    f.r0 = f.r1 = f.r2 = f.r3 = f.r4 = make_float4(0, 0, 0, 0);
-    f.r5 = make_float4(0, 0, __int_as_float(0x7fffffff), 0);
+  } else {  // padding: never passes its (empty) face box; a far-away point in any case
+    const gq3 far = gq_mk(1e18f, 1e18f, 1e18f);
+    f = gq_make_face(far, far, far, 0x7fffffff);
   }
   float4* o = rec + (size_t)6 * i;
   o[0] = f.r0; o[1] = f.r1; o[2] = f.r2; o[3] = f.r3; o[4] = f.r4; o[5] = f.r5;

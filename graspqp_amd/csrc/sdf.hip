@@ -461,8 +461,8 @@ __global__ void gq_occ_faces_kernel(const GqFace* __restrict__ rec, const int32_
   int m = 0;
   while (m + 1 < n_mesh && f >= off[m + 1]) ++m;
   const GqFace fc = rec[f];
-  const gq3 a = gq_mk(fc.r0.x, fc.r0.y, fc.r0.z);
-  const gq3 b = a + gq_mk(fc.r1.x, fc.r1.y, fc.r1.z), c = a + gq_mk(fc.r2.x, fc.r2.y, fc.r2.z);
+  gq3 a, b, c;
+  gq_face_corners(fc, a, b, c);
   const float* bb = aabb + m * 8;
   const float sc[3] = {bb[3], bb[7], invz[m]};
   const float lo[3] = {fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z)};

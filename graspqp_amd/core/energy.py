@@ -7,15 +7,18 @@ backward kernels, so a ``fit.py``-style loop (``new_energy.sum().backward()``) w
 
 import torch
 
+from .. import ops
+
 
 def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[], method="gendexgrasp", svd_gain=0.1):
     losses = {}
     distance, contact_normal = object_model.cal_distance(hand_model.contact_points)
-    if method == "dexgraspnet":
-        losses["E_dis"] = torch.sum(distance.abs(), dim=-1, dtype=torch.float)
-    elif method == "gendexgrasp":
-        nH = hand_model.contact_normals
-        losses["E_dis"] = ((1 - torch.sum((-contact_normal) * nH, dim=-1)).exp() * distance.abs()).sum(-1)
+    # (each term below is one launch that also writes its derivative, csrc/terms.hip: the torch expressions of the
+    # reference, energy.py:25-28,47-52,58-61, cost a dozen launches each, forward and backward, in a host-bound loop)
+    if method == "dexgraspnet":  # sum |d|
+        losses["E_dis"] = ops.energy_dis(distance, contact_normal, hand_model.contact_normals, with_normals=False)
+    elif method == "gendexgrasp":  # sum exp(1 - (-n_obj . n_hand)) |d|
+        losses["E_dis"] = ops.energy_dis(distance, contact_normal, hand_model.contact_normals, with_normals=True)
     else:
         raise ValueError(f"Unknown method: {method}")
 
@@ -23,15 +26,11 @@ def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[],
                                cog=object_model.cog, with_solution=True, svd_gain=svd_gain)
     losses["E_fc"] = E_fc
 
-    th = hand_model.hand_pose[:, 9:]
-    losses["E_joints"] = torch.sum((th > hand_model.joints_upper) * (th - hand_model.joints_upper), dim=-1) + torch.sum(
-        (th < hand_model.joints_lower) * (hand_model.joints_lower - th), dim=-1
-    )
+    losses["E_joints"] = ops.energy_joints(hand_model.hand_pose, hand_model.joints_lower, hand_model.joints_upper)
 
     object_model.attach(hand_model)
     distances = hand_model.cal_distance(object_model.surface_points_each, penetration_only=True)  # only dis > 0 is used
-    distances = torch.where(distances <= 0, torch.zeros_like(distances), distances)
-    losses["E_pen"] = distances.sum(-1)
+    losses["E_pen"] = ops.energy_pen(distances)  # sum of where(distances <= 0, 0, distances)
     losses["E_spen"] = hand_model.self_penetration()
 
     if "E_prior" in energy_names:  # energy.py:68-74: the grasp axis should point down

@@ -107,8 +107,7 @@ class ObjectModel:
     def cal_distance(self, x, with_closest_points=False):
         _, n_points, _ = x.shape
         d2, sgn, nrm, cls = ops.sdf_meshset(x.reshape(-1, 3), self._meshset, self.batch_size_each * n_points)
-        dis = torch.sqrt(d2 + 1e-8) * (-sgn)
-        normals = nrm * sgn.unsqueeze(1)
+        dis, normals = ops.signed_distance(d2, sgn, nrm)  # sqrt(d2 + 1e-8) * (-sgn), nrm * sgn
         distance = dis.reshape(-1, n_points)
         normals = normals.reshape(-1, n_points, 3)
         if with_closest_points:

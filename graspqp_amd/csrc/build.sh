@@ -29,7 +29,7 @@ deps() {  # headers each translation unit includes
     *) echo "common.h" ;;
   esac
 }
-for f in api qp qp_lr qp_dense qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf bvh kin fc fcstep stage loop export init metric; do
+for f in api qp qp_lr qp_dense qp_nz16 qp_nz32 qp_nz48 qp_nz64 sdf bvh kin fc fcstep stage loop export init metric terms; do
   stale=0
   [ -f "$OUT/$f.o" ] || stale=1
   for d in $f.hip $(deps $f); do [ "$HERE/$d" -nt "$OUT/$f.o" ] && stale=1; done

@@ -6,9 +6,17 @@ device only, fake kernels for tracing, ``register_autograd`` for the backward --
 visible to ``torch.compile`` / the profiler like any ATen op.  Their differentiability contracts are exactly those of
 the packages they replace: TorchSDF (only ``dist_sq`` w.r.t. ``points``), qpth (implicit KKT backward),
 pytorch_kinematics (full FK).  Opaque device objects (mesh sets, hands) cross the dispatcher as integer ids.
+
+Eager calls do not take the round trip through the dispatcher: a registered Python op costs ~40 us of host time per call
+(schema matching, re-dispatch, the autograd wrapper of torch.library), a ``fit.py``-shaped loop on the class surface makes
+about a dozen such calls per iteration, forward and backward, and is host-bound.  ``_Eager.<op>`` runs the SAME forward
+body, ``setup_context`` and backward that are registered -- through a plain ``torch.autograd.Function`` where the op has a
+gradient -- unless a trace / ``torch.compile`` is in progress or ``GRASPQP_DISPATCH=dispatcher`` / ``use_dispatcher(True)``
+asks for the registered route (tests compare the two bit for bit).
 """
 
 import ctypes
+import os
 import weakref
 from typing import List, Tuple
 
@@ -19,6 +27,47 @@ from torch import Tensor
 from . import _C
 
 _custom_op = torch.library.custom_op
+_ROUTE = {"dispatcher": os.environ.get("GRASPQP_DISPATCH", "eager") == "dispatcher"}
+
+
+def use_dispatcher(flag: bool) -> bool:
+    """Route eager calls through the registered ``torch.ops.graspqp_amd.*`` (True) or past the dispatcher (False, the
+    default; module docstring).  Returns the previous setting."""
+    old, _ROUTE["dispatcher"] = _ROUTE["dispatcher"], bool(flag)
+    return old
+
+
+class _Eager:
+    """Namespace of the eager routes, one per registered op (filled by ``_eager`` next to each registration)."""
+
+
+def _eager(name, opdef, bwd=None, setup=None):
+    body = opdef._init_fn  # the undecorated forward body
+    if bwd is None:
+        direct = body
+    else:
+        class _Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, *args):
+                out = body(*args)
+                setup(ctx, args, out)
+                return out
+
+            @staticmethod
+            def backward(ctx, *grads):
+                return bwd(ctx, *grads)
+
+        _Fn.__name__ = _Fn.__qualname__ = "graspqp_amd_" + name
+        direct = _Fn.apply
+    registered = getattr(torch.ops.graspqp_amd, name)
+
+    def call(*args):
+        if _ROUTE["dispatcher"] or torch.compiler.is_compiling():
+            return registered(*args)
+        return direct(*args)
+
+    call.__name__ = name
+    setattr(_Eager, name, staticmethod(call))
 _HANDLES = weakref.WeakValueDictionary()  # id -> MeshSet / HandHandle (ops take the id: only tensors and scalars may
 _next_id = [1]                            # cross the dispatcher)
 
@@ -228,7 +277,7 @@ def _sdf_setup(ctx, inputs, output):
 
 def _sdf_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
     pts, cls = ctx.saved_tensors
-    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls), None
+    return _Eager.sdf_backward(g_d2, pts, cls), None
 
 
 torch.library.register_autograd("graspqp_amd::compute_sdf", _sdf_bwd, setup_context=_sdf_setup)
@@ -278,10 +327,10 @@ def compute_sdf(points: torch.Tensor, face_verts: torch.Tensor):
     N, F = points.shape[0], face_verts.shape[0]
     if N > 0 and not face_verts.requires_grad:
         if N >= _BVH_MIN_QUERIES and _BVH_MIN_FACES <= F <= _BVH_MAX_FACES:
-            return torch.ops.graspqp_amd.sdf_bvh(points, _cached(face_verts, "bvh").hid)
+            return _Eager.sdf_bvh(points, _cached(face_verts, "bvh").hid)
         if F >= _MESH_CACHE_MIN_FACES:
-            return torch.ops.graspqp_amd.sdf_meshset(points, _cached_meshset(face_verts).hid, N)
-    return torch.ops.graspqp_amd.compute_sdf(points, face_verts)
+            return _Eager.sdf_meshset(points, _cached_meshset(face_verts).hid, N)
+    return _Eager.compute_sdf(points, face_verts)
 
 
 @_custom_op("graspqp_amd::sdf_meshset", mutates_args=(), device_types="cuda")
@@ -307,7 +356,7 @@ def _sdf_ms_setup(ctx, inputs, output):
 
 def _sdf_ms_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
     pts, cls = ctx.saved_tensors
-    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None, None
+    return _Eager.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None, None
 
 
 torch.library.register_autograd("graspqp_amd::sdf_meshset", _sdf_ms_bwd, setup_context=_sdf_ms_setup)
@@ -330,14 +379,14 @@ def _(points, bvh):
 
 def _sdf_bvh_bwd(ctx, g_d2, g_sgn, g_nrm, g_cls):
     pts, cls = ctx.saved_tensors
-    return torch.ops.graspqp_amd.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None
+    return _Eager.sdf_backward(g_d2, pts, cls).reshape(ctx.in_shape), None
 
 
 torch.library.register_autograd("graspqp_amd::sdf_bvh", _sdf_bvh_bwd, setup_context=_sdf_ms_setup)
 
 
 def sdf_meshset(points, meshset: MeshSet, queries_per_mesh: int):
-    return torch.ops.graspqp_amd.sdf_meshset(points, meshset.hid, int(queries_per_mesh))
+    return _Eager.sdf_meshset(points, meshset.hid, int(queries_per_mesh))
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -394,7 +443,7 @@ def _box_qp_setup(ctx, inputs, output):
 def _box_qp_bwd(ctx, gx, g_lam, g_slack, g_nit):
     Qc, x, lam, slack = ctx.saved_tensors
     nz = x.shape[1]
-    dx, dlam = torch.ops.graspqp_amd.box_qp_backward(Qc, lam, slack, gx)
+    dx, dlam = _Eager.box_qp_backward(Qc, lam, slack, gx)
     gQ = 0.5 * (dx.unsqueeze(2) * x.unsqueeze(1) + x.unsqueeze(2) * dx.unsqueeze(1))
     # h = [upper; -lower]; grad_h = -dlam
     return gQ, dx, dlam[:, nz:], -dlam[:, :nz], None, None, None
@@ -405,7 +454,7 @@ torch.library.register_autograd("graspqp_amd::box_qp", _box_qp_bwd, setup_contex
 
 def box_qp(Q, p, lower, upper, eps=5e-2, max_iter=12, not_improved_lim=3):
     """argmin 1/2 x'Qx + p'x, lower <= x <= upper -> (x, lam, slack); differentiable (qpth semantics)."""
-    x, lam, slack, _ = torch.ops.graspqp_amd.box_qp(Q, p, lower, upper, float(eps), int(max_iter), int(not_improved_lim))
+    x, lam, slack, _ = _Eager.box_qp(Q, p, lower, upper, float(eps), int(max_iter), int(not_improved_lim))
     return x, lam, slack
 
 
@@ -456,7 +505,7 @@ def _lsq_setup(ctx, inputs, output):
 
 def _lsq_bwd(ctx, gx, g_lam, g_slack, g_nit):
     Ac, bc, x, lam, slack = ctx.saved_tensors
-    dx, _ = torch.ops.graspqp_amd.lsq_box_qp_backward(Ac, lam, slack, gx, ctx.ridge)
+    dx, _ = _Eager.lsq_box_qp_backward(Ac, lam, slack, gx, ctx.ridge)
     # Q = A'A + ridge I -> grad_A = A (dx x' + x dx');  p = -A'b -> grad_A += -b dx', grad_b = -A dx
     Adx = (Ac @ dx.unsqueeze(-1)).squeeze(-1)
     Ax = (Ac @ x.unsqueeze(-1)).squeeze(-1)
@@ -471,7 +520,7 @@ def lsq_box_qp(A, b, lower, upper, ridge=1e-4, eps=5e-2, max_iter=12, return_n_i
     """x (B,nz); with ``return_n_iter`` also the (1,) int32 iteration count of qpth's batch-global stop rule."""
     if b is None:
         b = torch.zeros(A.shape[0], A.shape[1], device=A.device, dtype=A.dtype)
-    x, _, _, nit = torch.ops.graspqp_amd.lsq_box_qp(A, b, float(lower), float(upper), float(ridge), float(eps), int(max_iter))
+    x, _, _, nit = _Eager.lsq_box_qp(A, b, float(lower), float(upper), float(ridge), float(eps), int(max_iter))
     return (x, nit) if return_n_iter else x
 
 
@@ -530,7 +579,7 @@ def _fc_setup(ctx, inputs, output):
 def _fc_bwd(ctx, ge, g_xs, g_nit, g_ws):
     cp, cn, cg, ws = ctx.saved_tensors
     k, mu, tw, _ml, sg, vg, _eps, _mi = ctx.cfg
-    gp = torch.ops.graspqp_amd.fc_energy_backward(cp, cn, cg, ge, ws, k, mu, tw, sg, vg)
+    gp = _Eager.fc_energy_backward(cp, cn, cg, ge, ws, k, mu, tw, sg, vg)
     return (gp,) + (None,) * 10
 
 
@@ -545,7 +594,7 @@ def fc_energy(contact_pts, contact_normals, cog, return_n_iter=False, **cfg):
     """E_fc (B,) and per-contact force sums (B,n); gradient flows to contact_pts only (normals are SDF constants)."""
     c = dict(FC_DEFAULTS)
     c.update(cfg)
-    e, xs, nit, _ = torch.ops.graspqp_amd.fc_energy(
+    e, xs, nit, _ = _Eager.fc_energy(
         contact_pts, contact_normals.detach(), cog.detach(), int(c["n_cone_vecs"]), float(c["friction"]),
         float(c["torque_weight"]), float(c["max_limit"]), float(c["svd_gain"]), float(c["values_gain"]), float(c["eps"]),
         int(c["max_iter"]))
@@ -607,11 +656,11 @@ torch.library.register_autograd("graspqp_amd::tdg_energy", _alt_bwd, setup_conte
 
 def dexgrasp_energy(contact_pts, contact_normals, cog, torque_weight=0.0):
     """(B,) DexGraspNet force-closure term; gradient to contact_pts (the normals are SDF constants)."""
-    return torch.ops.graspqp_amd.dexgrasp_energy(contact_pts, contact_normals.detach(), cog.detach(), float(torque_weight))[0]
+    return _Eager.dexgrasp_energy(contact_pts, contact_normals.detach(), cog.detach(), float(torque_weight))[0]
 
 
 def tdg_energy(contact_pts, contact_normals, cog, directions, friction=0.2, obb_length=0.2, enable_density=True, scale=100.0):
-    return torch.ops.graspqp_amd.tdg_energy(contact_pts, contact_normals.detach(), cog.detach(), directions, float(friction),
+    return _Eager.tdg_energy(contact_pts, contact_normals.detach(), cog.detach(), directions, float(friction),
                                             float(obb_length), bool(enable_density), float(scale))[0]
 
 
@@ -732,7 +781,7 @@ def _(hand, hand_pose, idx, Rg, LT, ws, gcp, gcn, gsc, wrench, gRt, gR, has):
 def _fk_backward(hand, hp, ix, Rg, LT, ws, gcp=None, gcn=None, gsc=None, wrench=None, gRt=None, gR=None):
     z = hp.new_empty(0)
     args = [gcp, gcn, gsc, wrench, gRt, gR]
-    return torch.ops.graspqp_amd.fk_backward(hand.hid, hp, ix, Rg, LT, ws, *[z if a is None else a for a in args],
+    return _Eager.fk_backward(hand.hid, hp, ix, Rg, LT, ws, *[z if a is None else a for a in args],
                                              [a is not None for a in args])
 
 
@@ -756,7 +805,7 @@ def fk_contacts(hand_pose, idx, hand: HandHandle):
     """-> (Rg (B,3,3), link_T (B,L,3,4), contact_points, contact_normals, sphere_centers, fk workspace)."""
     if not hand_pose.is_cuda:
         raise RuntimeError("graspqp_amd ops need CUDA (ROCm) tensors; got a CPU tensor")
-    return torch.ops.graspqp_amd.fk_contacts(hand_pose, idx, hand.hid)
+    return _Eager.fk_contacts(hand_pose, idx, hand.hid)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -873,7 +922,7 @@ class _HandPen(torch.autograd.Function):
     def forward(ctx, hand_pose, surface_points, batch_each, hand, idx, Rg, LT, ws, penetration_only):
         hp = _c(hand_pose.detach())
         sp = _c(surface_points)
-        dis, link, gvec = torch.ops.graspqp_amd.hand_pen(hp, sp, batch_each, hand.hid, Rg, LT, penetration_only)
+        dis, link, gvec = _Eager.hand_pen(hp, sp, batch_each, hand.hid, Rg, LT, penetration_only)
         ctx.save_for_backward(hp, sp, idx, Rg, LT, ws, link, gvec)
         ctx.hand, ctx.batch_each = hand, batch_each
         return dis
@@ -882,7 +931,7 @@ class _HandPen(torch.autograd.Function):
     def backward(ctx, g):
         hp, sp, idx, Rg, LT, ws, link, gvec = ctx.saved_tensors
         hand = ctx.hand
-        wrench, gRt = torch.ops.graspqp_amd.hand_pen_backward(hand.L, sp, ctx.batch_each, hp, Rg, g, link, gvec)
+        wrench, gRt = _Eager.hand_pen_backward(hand.L, sp, ctx.batch_each, hp, Rg, g, link, gvec)
         gp = _fk_backward(hand, hp, idx, Rg, LT, ws, None, None, None, wrench, gRt, None)
         return gp, None, None, None, None, None, None, None, None
 
@@ -919,4 +968,169 @@ torch.library.register_autograd("graspqp_amd::self_pen", _self_pen_bwd, setup_co
 def self_pen(centers, hand: HandHandle):
     if hand.S == 0:
         return torch.zeros(centers.shape[0], device=centers.device)
-    return torch.ops.graspqp_amd.self_pen(centers, hand.hid)[0]
+    return _Eager.self_pen(centers, hand.hid)[0]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# energy terms of the class surface, one launch each (csrc/terms.hip): the forward launch also writes the term's
+# derivative, the backward is a broadcast multiply with the upstream row gradient
+# ----------------------------------------------------------------------------------------------------------
+@_custom_op("graspqp_amd::signed_distance", mutates_args=(), device_types="cuda")
+def _signed_distance_op(dist_sq: Tensor, sign: Tensor, normal: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """ObjectModel.cal_distance (object_model.py:222-227): (sqrt(dist_sq + 1e-8) * (-sign), normal * sign, d dis / d dist_sq)."""
+    d2, sg, nr = _c(dist_sq), _c(sign, torch.int32), _c(normal)
+    dis, nout, g = torch.empty_like(d2), torch.empty_like(nr), torch.empty_like(d2)
+    _C.call("gq_signed_distance", _C.f32(d2), _C.i32(sg), _C.f32(nr), d2.numel(), _C.f32(dis), _C.f32(nout), _C.f32(g),
+            _C.stream_ptr())
+    return dis, nout, g
+
+
+@_signed_distance_op.register_fake
+def _(dist_sq, sign, normal):
+    return torch.empty_like(dist_sq), torch.empty_like(normal), torch.empty_like(dist_sq)
+
+
+def _signed_distance_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[2])
+    ctx.mark_non_differentiable(output[1], output[2])
+
+
+def _signed_distance_bwd(ctx, g_dis, g_n, g_g):
+    (g,) = ctx.saved_tensors
+    return g_dis * g, None, None
+
+
+torch.library.register_autograd("graspqp_amd::signed_distance", _signed_distance_bwd, setup_context=_signed_distance_setup)
+
+
+def signed_distance(dist_sq, sign, normal):
+    dis, nout, _ = _Eager.signed_distance(dist_sq, sign, normal)
+    return dis, nout
+
+
+@_custom_op("graspqp_amd::energy_dis", mutates_args=(), device_types="cuda")
+def _energy_dis_op(distance: Tensor, obj_normal: Tensor, hand_normal: Tensor, with_normals: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """E_dis (energy.py:25-28): with_normals ("gendexgrasp") sum_j exp(1 - (-n_obj . n_hand)) |d|, else sum_j |d|;
+    -> (e (B,), d e / d distance (B,n), d e / d hand_normal (B,n,3))."""
+    d = _c(distance)
+    B, n = d.shape
+    e, gd = torch.empty(B, device=d.device), torch.empty_like(d)
+    if with_normals:
+        on, hn = _c(obj_normal), _c(hand_normal)
+        gh = torch.empty_like(hn)
+        _C.call("gq_energy_dis", _C.f32(d), _C.f32(on), _C.f32(hn), B, n, _C.f32(e), _C.f32(gd), _C.f32(gh), _C.stream_ptr())
+    else:
+        gh = d.new_zeros(B, n, 3)
+        _C.call("gq_energy_dis", _C.f32(d), None, None, B, n, _C.f32(e), _C.f32(gd), None, _C.stream_ptr())
+    return e, gd, gh
+
+
+@_energy_dis_op.register_fake
+def _(distance, obj_normal, hand_normal, with_normals):
+    B, n = distance.shape
+    return distance.new_empty(B), torch.empty_like(distance), distance.new_empty(B, n, 3)
+
+
+def _energy_dis_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], output[2])
+    ctx.with_normals = bool(inputs[3])
+    ctx.mark_non_differentiable(output[1], output[2])
+
+
+def _energy_dis_bwd(ctx, ge, g1, g2):
+    gd, gh = ctx.saved_tensors
+    return ge.unsqueeze(-1) * gd, None, (ge.view(-1, 1, 1) * gh) if ctx.with_normals else None, None
+
+
+torch.library.register_autograd("graspqp_amd::energy_dis", _energy_dis_bwd, setup_context=_energy_dis_setup)
+
+
+def energy_dis(distance, obj_normal, hand_normal, with_normals=True):
+    return _Eager.energy_dis(distance, obj_normal.detach(), hand_normal, bool(with_normals))[0]
+
+
+@_custom_op("graspqp_amd::energy_joints", mutates_args=(), device_types="cuda")
+def _energy_joints_op(hand_pose: Tensor, lower: Tensor, upper: Tensor) -> Tuple[Tensor, Tensor]:
+    """E_joints (energy.py:47-52) over the last len(lower) columns of hand_pose -> (e (B,), d e / d hand_pose (B,D))."""
+    hp, lo, hi = _c(hand_pose), _c(lower), _c(upper)
+    B, D = hp.shape
+    e, g = torch.empty(B, device=hp.device), torch.empty_like(hp)
+    _C.call("gq_energy_joints", _C.f32(hp), _C.f32(lo), _C.f32(hi), B, D, lo.numel(), _C.f32(e), _C.f32(g), _C.stream_ptr())
+    return e, g
+
+
+@_energy_joints_op.register_fake
+def _(hand_pose, lower, upper):
+    return hand_pose.new_empty(hand_pose.shape[0]), torch.empty_like(hand_pose)
+
+
+def _energy_joints_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.mark_non_differentiable(output[1])
+
+
+def _energy_joints_bwd(ctx, ge, g1):
+    (g,) = ctx.saved_tensors
+    return ge.unsqueeze(-1) * g, None, None
+
+
+torch.library.register_autograd("graspqp_amd::energy_joints", _energy_joints_bwd, setup_context=_energy_joints_setup)
+
+
+def energy_joints(hand_pose, lower, upper):
+    return _Eager.energy_joints(hand_pose, lower, upper)[0]
+
+
+@_custom_op("graspqp_amd::energy_pen", mutates_args=(), device_types="cuda")
+def _energy_pen_op(distances: Tensor) -> Tensor:
+    """E_pen (energy.py:58-61): sum over the surface points of where(distances <= 0, 0, distances) -> (B,)."""
+    d = _c(distances)
+    B, P = d.shape
+    e = torch.empty(B, device=d.device)
+    _C.call("gq_energy_pen", _C.f32(d), B, P, _C.f32(e), _C.stream_ptr())
+    return e
+
+
+@_energy_pen_op.register_fake
+def _(distances):
+    return distances.new_empty(distances.shape[0])
+
+
+def _energy_pen_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+
+
+def _energy_pen_bwd(ctx, ge):
+    (d,) = ctx.saved_tensors
+    return torch.where(d > 0, ge.unsqueeze(-1), ge.new_zeros(()))
+
+
+torch.library.register_autograd("graspqp_amd::energy_pen", _energy_pen_bwd, setup_context=_energy_pen_setup)
+
+
+def energy_pen(distances):
+    return _Eager.energy_pen(distances)
+
+
+# eager routes of the registered ops (see the module docstring)
+_eager("sdf_backward", _sdf_backward)
+_eager("compute_sdf", _compute_sdf_op, _sdf_bwd, _sdf_setup)
+_eager("sdf_meshset", _sdf_meshset_op, _sdf_ms_bwd, _sdf_ms_setup)
+_eager("sdf_bvh", _sdf_bvh_op, _sdf_bvh_bwd, _sdf_ms_setup)
+_eager("box_qp", _box_qp_op, _box_qp_bwd, _box_qp_setup)
+_eager("box_qp_backward", _box_qp_bwd_op)
+_eager("lsq_box_qp", _lsq_box_qp_op, _lsq_bwd, _lsq_setup)
+_eager("lsq_box_qp_backward", _lsq_box_qp_bwd_op)
+_eager("fc_energy", _fc_energy_op, _fc_bwd, _fc_setup)
+_eager("fc_energy_backward", _fc_energy_bwd_op)
+_eager("dexgrasp_energy", _dexgrasp_op, _alt_bwd, _alt_setup)
+_eager("tdg_energy", _tdg_op, _alt_bwd, _alt_setup)
+_eager("fk_contacts", _fk_op, _fk_bwd, _fk_setup)
+_eager("fk_backward", _fk_bwd_op)
+_eager("hand_pen", _hand_pen_op)
+_eager("hand_pen_backward", _hand_pen_bwd_op)
+_eager("self_pen", _self_pen_op, _self_pen_bwd, _self_pen_setup)
+_eager("signed_distance", _signed_distance_op, _signed_distance_bwd, _signed_distance_setup)
+_eager("energy_dis", _energy_dis_op, _energy_dis_bwd, _energy_dis_setup)
+_eager("energy_joints", _energy_joints_op, _energy_joints_bwd, _energy_joints_setup)
+_eager("energy_pen", _energy_pen_op, _energy_pen_bwd, _energy_pen_setup)

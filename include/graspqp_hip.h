@@ -387,6 +387,25 @@ int gq_row_energy(const float* dist_sq, const int32_t* sign, const float* onrm, 
                   int64_t n_surface, float w_dis, float w_fc, float w_pen, float w_spen, float w_joints, float* e_dis,
                   float* e_joints, float* e_pen, float* total, float* g_theta /* (B,J) */, float* g_pen /* (B,P) */,
                   void* stream);
+/* The same terms one by one, each with its derivative, for the autograd route of the class surface (calculate_energy on
+ * HandModel / ObjectModel): the derivative is written by the forward launch and the backward is a broadcast multiply with
+ * the upstream row gradient -- one launch per term where the reference's torch expressions issue a dozen.
+ *   gq_signed_distance: ObjectModel.cal_distance, core/object_model.py:222-227 -- distance = sqrt(dist_sq + 1e-8) * (-sign),
+ *                       normal_out = normal_in * sign, g_dist_sq = d distance / d dist_sq; n = number of queries.
+ *   gq_energy_dis:      core/energy.py:25-28 -- "gendexgrasp": e = sum_j exp(1 - (-obj_normal . hand_normal)) |distance|,
+ *                       g_distance = d e / d distance, g_hand_normal = d e / d hand_normal; obj_normal == NULL selects the
+ *                       "dexgraspnet" form e = sum_j |distance| (hand_normal / g_hand_normal unused).
+ *   gq_energy_joints:   core/energy.py:47-52 -- e = sum relu(theta - upper) + relu(lower - theta) over the last n_dofs
+ *                       columns of hand_pose; g_hand_pose (B, pose_dim) = d e / d hand_pose (zero in the root columns).
+ *   gq_energy_pen:      core/energy.py:58-61 -- e = sum_p where(distances <= 0, 0, distances).                            */
+int gq_signed_distance(const float* dist_sq, const int32_t* sign, const float* normal_in, int64_t n, float* distance,
+                       float* normal_out, float* g_dist_sq, void* stream);
+int gq_energy_dis(const float* distance /* (B,n) */, const float* obj_normal /* (B,n,3) or NULL */,
+                  const float* hand_normal /* (B,n,3) */, int64_t batch, int n_contact, float* e_dis /* (B) */,
+                  float* g_distance /* (B,n) */, float* g_hand_normal /* (B,n,3) */, void* stream);
+int gq_energy_joints(const float* hand_pose, const float* joints_lower, const float* joints_upper, int64_t batch, int pose_dim,
+                     int n_dofs, float* e_joints /* (B) */, float* g_hand_pose /* (B,pose_dim) */, void* stream);
+int gq_energy_pen(const float* distances /* (B,P) */, int64_t batch, int64_t n_surface, float* e_pen /* (B) */, void* stream);
 int gq_axpy(float* y, const float* x, float a, int64_t n, void* stream);
 int gq_scale(float* y, const float* x, float a, int64_t n, void* stream);
 int gq_fill(float* y, float a, int64_t n, void* stream);

@@ -575,6 +575,60 @@ def test_energy_and_gradient_match_golden(gq, golden_dir, tag, n):
     assert np.linalg.norm(ga - gg) / np.linalg.norm(gg) < 1e-4
 
 
+def test_eager_route_equals_the_registered_ops(gq, golden_dir):
+    """The class surface calls the forward bodies / backwards of the registered ops directly (ops._Eager: no dispatcher
+    round trip per call); ``ops.use_dispatcher(True)`` sends the same calls through ``torch.ops.graspqp_amd.*``.  One
+    energy + gradient evaluation of the fixture scene on both routes, plus compute_sdf and QPFunction with gradients: the
+    same kernels on the same inputs, bit for bit."""
+    from graspqp_amd.core.energy import calculate_energy
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.core.object_model import ObjectModel
+    from graspqp_amd.metrics import GraspSpanMetricFactory as GF
+    from graspqp_amd.metrics import QPFunction
+
+    g = _load(golden_dir, "energy_allegro_sq_b6_n12.npz")
+    pose_key, idx_key = "hand_pose", "contact_idx"
+    n_obj = int(g["n_obj"])
+    spec = get_hand_spec("allegro")
+    names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints"]
+    w = {"E_dis": 100.0, "E_fc": 1.0, "E_pen": 100.0, "E_spen": 10.0, "E_joints": 1.0}
+    rng = np.random.default_rng(2)
+    fv = torch.tensor(meshes.icosphere(2, 0.05), dtype=torch.float32).cuda()
+    pts0 = torch.tensor(rng.normal(size=(500, 3)) * 0.06, dtype=torch.float32).cuda()
+    A = torch.tensor(rng.normal(size=(16, 6, 24)), dtype=torch.float32).cuda()
+    res = {}
+    for route in (False, True):
+        old = gq.ops.use_dispatcher(route)
+        try:
+            hm = HandModel(spec, "cuda")
+            om = ObjectModel(batch_size_each=int(g["batch_size_each"]), num_samples=g["obj0_surface_points"].shape[0])
+            om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                                      surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+            hp = torch.tensor(g[pose_key], dtype=torch.float32).cuda().requires_grad_()
+            hm.set_parameters(hp, torch.tensor(g[idx_key]).cuda())
+            fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+            losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+            tot = sum(w[k] * v for k, v in losses.items())
+            tot.sum().backward()
+            pts = pts0.clone().requires_grad_()
+            d2, sg, nrm, cls = gq.ops.compute_sdf(pts, fv)
+            d2.sum().backward()
+            Aq = A.clone().requires_grad_()
+            Q = Aq.transpose(1, 2) @ Aq + 1e-4 * torch.eye(24, device="cuda")
+            pq = -(Aq.transpose(1, 2) @ torch.ones(16, 6, 1, device="cuda")).squeeze(-1)
+            G = torch.cat([torch.eye(24), -torch.eye(24)]).cuda().expand(16, -1, -1)
+            hq = torch.cat([torch.full((16, 24), 2.0), torch.zeros(16, 24)], 1).cuda()
+            x = QPFunction(maxIter=12, eps=5e-2)(Q, pq, G, hq)
+            x.square().sum().backward()
+            torch.cuda.synchronize()
+            res[route] = [tot.detach(), hm.hand_pose.grad.clone(), *[losses[k].detach() for k in names], d2.detach(), sg, nrm,
+                          cls, pts.grad.clone(), x.detach(), Aq.grad.clone()]
+        finally:
+            gq.ops.use_dispatcher(old)
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+
+
 def test_mala_iterations_match_reference_optimizer(gq, golden_dir):
     """fit.py loop order + MalaStar semantics against the fixture produced by the reference's own optimizer.py.
 
@@ -1022,6 +1076,95 @@ def test_torch_library_ops_opcheck(gq, golden_dir):
     (g1,) = torch.autograd.grad(e.sum(), cp)
     (g2,) = torch.autograd.grad(e2.sum(), cp)
     assert torch.equal(g1, g2)
+
+
+def test_kernels_launch_on_torchs_current_stream(gq):
+    """_C.stream_ptr() hands the C ABI torch's CURRENT stream (raw handle): a side stream entered with torch.cuda.stream()
+    is the one the kernels are launched on, and leaving the context returns to the default stream."""
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream().cuda_stream
+    assert (gq.C.stream_ptr().value or 0) == main
+    with torch.cuda.stream(side):
+        assert gq.C.stream_ptr().value == side.cuda_stream
+        x = torch.zeros(1 << 20, device="cuda")
+        gq.C.call("gq_fill", gq.C.f32(x), 3.0, x.numel(), gq.C.stream_ptr())
+    side.synchronize()
+    assert (gq.C.stream_ptr().value or 0) == main and float(x.min()) == 3.0
+
+
+def test_class_surface_term_ops_equal_the_reference_expressions(gq):
+    """The one-launch energy terms of the class surface (csrc/terms.hip: E_dis in both `method` forms, E_joints, E_pen, the
+    signed distance of ObjectModel.cal_distance) against the torch expressions of the reference (core/energy.py:25-28,
+    47-52,58-61; core/object_model.py:222-227) in fp64: values and gradients under a random upstream, ragged sizes, exact
+    zeros and sign changes included; opcheck on the registered ops."""
+    rng = np.random.default_rng(3)
+    t = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device="cuda")
+    B, n, P, J = 37, 12, 2500, 16
+    dist = rng.normal(size=(B, n)) * 0.02
+    dist[0, :3] = 0.0
+    on = rng.normal(size=(B, n, 3)); on /= np.linalg.norm(on, axis=-1, keepdims=True)
+    hn = rng.normal(size=(B, n, 3)); hn /= np.linalg.norm(hn, axis=-1, keepdims=True)
+    up = rng.uniform(0.5, 2.0, B)
+    for with_normals in (True, False):
+        d32, h32 = t(dist).requires_grad_(), t(hn).requires_grad_()
+        e = gq.ops.energy_dis(d32, t(on), h32, with_normals=with_normals)
+        (e * t(up)).sum().backward()
+        d64, h64 = t(dist, torch.float64).requires_grad_(), t(hn, torch.float64).requires_grad_()
+        if with_normals:
+            e64 = ((1 - torch.sum((-t(on, torch.float64)) * h64, dim=-1)).exp() * d64.abs()).sum(-1)
+        else:
+            e64 = torch.sum(d64.abs(), dim=-1)
+        (e64 * t(up, torch.float64)).sum().backward()
+        np.testing.assert_allclose(e.detach().cpu().numpy(), e64.detach().cpu().numpy(), rtol=5e-6)
+        np.testing.assert_allclose(d32.grad.cpu().numpy(), d64.grad.cpu().numpy(), rtol=5e-6, atol=1e-7)
+        if with_normals:
+            np.testing.assert_allclose(h32.grad.cpu().numpy(), h64.grad.cpu().numpy(), rtol=5e-6, atol=1e-8)
+        else:
+            assert h32.grad is None
+    lo, hi = -rng.uniform(0.2, 0.5, J), rng.uniform(0.5, 1.5, J)
+    pose = np.concatenate([rng.normal(size=(B, 9)), rng.uniform(-1.0, 2.0, size=(B, J))], 1)
+    pose[1, 9:] = hi      # exactly on the limits: inside
+    pose[2, 9:] = lo
+    p32 = t(pose).requires_grad_()
+    e = gq.ops.energy_joints(p32, t(lo), t(hi))
+    (e * t(up)).sum().backward()
+    p64 = t(pose, torch.float64).requires_grad_()
+    th, l64, h64 = p64[:, 9:], t(lo, torch.float64), t(hi, torch.float64)
+    e64 = torch.sum((th > h64) * (th - h64), dim=-1) + torch.sum((th < l64) * (l64 - th), dim=-1)
+    (e64 * t(up, torch.float64)).sum().backward()
+    np.testing.assert_allclose(e.detach().cpu().numpy(), e64.detach().cpu().numpy(), rtol=5e-6, atol=1e-7)
+    np.testing.assert_allclose(p32.grad.cpu().numpy(), p64.grad.cpu().numpy(), rtol=1e-6, atol=0)
+    pen = rng.normal(size=(B, P)) * 0.01 - 0.008
+    pen[3, :10] = 0.0
+    q32 = t(pen).requires_grad_()
+    e = gq.ops.energy_pen(q32)
+    (e * t(up)).sum().backward()
+    q64 = t(pen, torch.float64).requires_grad_()
+    e64 = torch.where(q64 <= 0, torch.zeros_like(q64), q64).sum(-1)
+    (e64 * t(up, torch.float64)).sum().backward()
+    np.testing.assert_allclose(e.detach().cpu().numpy(), e64.detach().cpu().numpy(), rtol=5e-6, atol=1e-8)
+    np.testing.assert_allclose(q32.grad.cpu().numpy(), q64.grad.cpu().numpy(), rtol=1e-6, atol=0)
+    N = 1000
+    d2 = np.abs(rng.normal(size=N)) * 1e-3
+    d2[:5] = 0.0
+    sg = rng.choice([-1, 1], N)
+    nr = rng.normal(size=(N, 3))
+    a32 = t(d2).requires_grad_()
+    dis, nout = gq.ops.signed_distance(a32, t(sg, torch.int32), t(nr))
+    (dis * t(rng.normal(size=N))).sum().backward()
+    a64 = t(d2, torch.float64).requires_grad_()
+    dis64 = torch.sqrt(a64 + 1e-8) * (-t(sg, torch.float64))
+    np.testing.assert_allclose(dis.detach().cpu().numpy(), dis64.detach().cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(nout.cpu().numpy(), nr.astype(np.float32) * sg[:, None].astype(np.float32), rtol=0, atol=0)
+    g64 = torch.autograd.grad(dis64, a64, torch.ones_like(dis64))[0]  # d dis / d d2, element-wise
+    g32 = torch.autograd.grad(gq.ops.signed_distance(a32, t(sg, torch.int32), t(nr))[0], a32, torch.ones(N, device="cuda"))[0]
+    np.testing.assert_allclose(g32.cpu().numpy(), g64.cpu().numpy(), rtol=5e-6)
+    utils = ("test_schema", "test_autograd_registration", "test_faketensor")
+    ns = torch.ops.graspqp_amd
+    torch.library.opcheck(ns.energy_dis, (t(dist).requires_grad_(), t(on), t(hn).requires_grad_(), True), test_utils=utils)
+    torch.library.opcheck(ns.energy_joints, (t(pose).requires_grad_(), t(lo), t(hi)), test_utils=utils)
+    torch.library.opcheck(ns.energy_pen, (t(pen).requires_grad_(),), test_utils=utils)
+    torch.library.opcheck(ns.signed_distance, (t(d2).requires_grad_(), t(sg, torch.int32), t(nr)), test_utils=utils)
 
 
 def test_reference_shaped_metric_call_with_solver_cls(gq, golden_dir):

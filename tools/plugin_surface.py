@@ -242,5 +242,8 @@ if __name__ == "__main__":
         r = sdf_calls(spec, hand, hp.cuda().float().contiguous(), idx.cuda().contiguous(), surf, 256, fv, 12)
         print(json.dumps({"lib": os.environ.get("GRASPQP_HIP_LIB", "default"), "hand_links_total_us": r["hand_links_total_us"],
                           "per_link_us": [round(x["us"], 1) for x in r["hand_links"]], "object_us": r["object"]["us"]}), flush=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "loop":  # the class-surface loop only (under rocprofv3: its kernel list)
+        print(json.dumps(class_surface_loop(spec, fv, sp, 256, 12, hp.cuda().float().contiguous(), idx.cuda().contiguous(),
+                                            iters=int(sys.argv[2]) if len(sys.argv) > 2 else 200)), flush=True)
     else:
         print(json.dumps(measure(spec, fv, sp, 256, 12, hp, idx)), flush=True)

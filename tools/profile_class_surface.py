@@ -31,8 +31,15 @@ def main():
     sp = meshes.surface_points(fv, 2500, oversample=4, seed=42)
     hp, idx = make_initial_state(spec, fv, 256, 12, 1000)
     hp, idx = hp.cuda().float(), idx.cuda()
-    r = ps.class_surface_loop(spec, fv, sp, 256, 12, hp, idx, iters=iters)
-    print("plain:", r["ms_per_iteration"], "ms / iteration")
+    from graspqp_amd import ops
+
+    for rep in range(2):
+        for route in (True, False):
+            old = ops.use_dispatcher(route)
+            r = ps.class_surface_loop(spec, fv, sp, 256, 12, hp, idx, iters=iters)
+            ops.use_dispatcher(old)
+            print("registered ops through the dispatcher:" if route else "eager route:", round(r["ms_per_iteration"], 4),
+                  "ms / iteration,", round(r["evals_per_s"]), "evals/s")
     pr = cProfile.Profile()
     pr.enable()
     r = ps.class_surface_loop(spec, fv, sp, 256, 12, hp, idx, iters=iters)

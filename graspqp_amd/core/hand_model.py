@@ -101,7 +101,8 @@ class HandModel:
             self.contact_point_indices = torch.where(env_mask.unsqueeze(-1), contact_point_indices, self.contact_point_indices)
         # reference hand_model.py:815-831: the contact points are gathered with the indices PASSED IN, also for the rows
         # outside env_mask (whose stored indices stay what they were) -- kept, it decides the energies of a reset iteration
-        Rg, LT, cp, cn, sc, ws = ops.fk_contacts(self.hand_pose, contact_point_indices.contiguous(), self._hand)
+        self._fk_idx = contact_point_indices.contiguous()  # the indices the kinematic state below belongs to
+        Rg, LT, cp, cn, sc, ws = ops.fk_contacts(self.hand_pose, self._fk_idx, self._hand)
         self._fk_ws = ws
         self.global_rotation = Rg
         self.current_status = LT

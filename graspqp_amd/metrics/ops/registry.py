@@ -39,6 +39,14 @@ class SpanMetricWrapper(torch.nn.Module):
         svd_gain = kwargs.pop("svd_gain", 0.1)
         values_gain = kwargs.pop("values_gain", 2.0)
         with_solution = kwargs.pop("with_solution", False)
+        e, xs = ops.fc_energy(contact_pts, contact_normals, cog, **self.fc_config(svd_gain, values_gain, torque_weight))
+        if with_solution:
+            return e, xs
+        return e
+
+    def fc_config(self, svd_gain=0.1, values_gain=2.0, torque_weight=5.0) -> dict:
+        """Keyword arguments of ``ops.fc_energy`` for this wrapper's metric_kwargs (resolved on first use, like the
+        reference's lazy metric construction, registry.py:44-52)."""
         if not self._initialized:
             self._max_limit = self.metric_kwargs.pop("max_limit", None)
             self._friction = self.metric_kwargs.pop("friction", None)
@@ -50,14 +58,8 @@ class SpanMetricWrapper(torch.nn.Module):
                                           "the HIP kernels implement (metrics/ops/span.py:298)")
             self._initialized = True
         max_limit = 50.0 if self._max_limit is None else self._max_limit  # span.py:28 default
-        e, xs = ops.fc_energy(
-            contact_pts, contact_normals, cog, friction=0.2 if self._friction is None else self._friction,
-            n_cone_vecs=self._n_cone, torque_weight=torque_weight, max_limit=max_limit, svd_gain=svd_gain,
-            values_gain=values_gain,
-        )
-        if with_solution:
-            return e, xs
-        return e
+        return dict(friction=0.2 if self._friction is None else self._friction, n_cone_vecs=self._n_cone,
+                    torque_weight=torque_weight, max_limit=max_limit, svd_gain=svd_gain, values_gain=values_gain)
 
 
 class GraspSpanMetricFactory:

@@ -625,8 +625,33 @@ def test_eager_route_equals_the_registered_ops(gq, golden_dir):
                           cls, pts.grad.clone(), x.detach(), Aq.grad.clone()]
         finally:
             gq.ops.use_dispatcher(old)
-    for a, b in zip(res[False], res[True]):
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        if i == 1:  # d total / d hand_pose: the eager route sums the terms' contributions inside ONE autograd node
+            assert float((a - b).norm() / b.norm()) < 2e-6  # (core/energy.py:_FusedTerms), autograd in another order
+        else:
+            assert torch.equal(a, b), i
+    # the fused node against the term-by-term composition on the eager route: same terms, bit for bit
+    from graspqp_amd.core import energy as energy_mod
+
+    outs = []
+    for fused in (True, False):
+        old, energy_mod.FUSED = energy_mod.FUSED, fused
+        try:
+            hm = HandModel(spec, "cuda")
+            om = ObjectModel(batch_size_each=int(g["batch_size_each"]), num_samples=g["obj0_surface_points"].shape[0])
+            om.initialize_from_meshes([g[f"obj{i}_face_verts"] for i in range(n_obj)],
+                                      surface_points_list=[g[f"obj{i}_surface_points"] for i in range(n_obj)])
+            hm.set_parameters(torch.tensor(g[pose_key], dtype=torch.float32).cuda().requires_grad_(), torch.tensor(g[idx_key]).cuda())
+            fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
+            up = torch.linspace(0.5, 1.5, hm.hand_pose.shape[0], device="cuda")  # a non-uniform upstream per row and term
+            losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+            sum((j + 1.0) * (losses[k] * up).sum() for j, k in enumerate(names)).backward()
+            outs.append([losses[k].detach() for k in names] + [hm.hand_pose.grad.clone()])
+        finally:
+            energy_mod.FUSED = old
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
         assert torch.equal(a, b)
+    assert float((outs[0][-1] - outs[1][-1]).norm() / outs[1][-1].norm()) < 2e-6
 
 
 def test_mala_iterations_match_reference_optimizer(gq, golden_dir):

@@ -502,7 +502,7 @@ def rank_main(args):
 
                 hp0, ix0 = make_initial_state(spec, fvs[0], args.batch_size, args.n_contact, 1000 + my_objs[0])
                 res["plugin_surface"] = plugin_surface.measure(spec, fvs[0], sps[0], args.batch_size, args.n_contact, hp0, ix0,
-                                                               loop_iters=60, reps=7)
+                                                               loop_iters=300, reps=7)
                 res["plugin_surface"]["stepper_evals_per_s"] = res["value"]
             except Exception as e:  # diagnostics must never cost the bench line
                 res["plugin_surface"] = {"error": repr(e)}

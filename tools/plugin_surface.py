@@ -163,8 +163,11 @@ def qp_calls(sizes=((256, 48), (2048, 48), (32768, 48), (256, 96), (2048, 96), (
     return out
 
 
-def class_surface_loop(spec, fv, sp, batch, n_contact, hp, idx, iters=60, warm=10):
-    """scripts/fit.py:399-458 on the class surface (autograd route): evals/s, no resets, no export."""
+def class_surface_loop(spec, fv, sp, batch, n_contact, hp, idx, iters=60, warm=None):
+    """scripts/fit.py:399-458 on the class surface (autograd route): evals/s, no resets, no export.  The loop is host-bound and
+    keeps the GPU ~40 % busy: the first ~100 iterations after a pause run at lower clocks (0.85 instead of 0.56 ms each), so
+    the warm-up is a third of the timed count (at least 10)."""
+    warm = max(10, iters // 3) if warm is None else warm
     from graspqp_amd.core.energy import calculate_energy
     from graspqp_amd.core.hand_model import HandModel
     from graspqp_amd.core.object_model import ObjectModel
@@ -208,6 +211,7 @@ def class_surface_loop(spec, fv, sp, batch, n_contact, hp, idx, iters=60, warm=1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"evals_per_s": batch * iters / dt, "ms_per_iteration": dt / iters * 1e3, "iterations": iters,
+            "warm_up_iterations": warm,
             "route": "HandModel / ObjectModel / calculate_energy / MalaStar (autograd, eager launches, host-driven)",
             "mean_energy": float(energy.mean())}
 

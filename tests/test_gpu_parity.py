@@ -217,6 +217,61 @@ def test_sdf_sliver_faces_are_classified_like_any_other_face(gq, width):
     np.testing.assert_allclose((p - cls).norm(dim=1).cpu().numpy(), np.sqrt(d2.cpu().numpy()), rtol=1e-4, atol=3e-8)
 
 
+def test_sdf_degenerate_faces_count_as_their_segments(gq):
+    """Zero-area faces (two or three coinciding corners, three collinear corners) in an otherwise regular mesh: the face
+    record of tri.h describes the segment such a face collapses to (its `gate` sends every query down the edge path), so the
+    distance is the distance to that segment, the sign is +1 (dot with a zero normal >= 0) and the normal is the direction
+    to the closest point -- for the face loop and for the box hierarchy, against segment distances computed in fp64."""
+    rng = np.random.default_rng(9)
+    reg = meshes.icosphere(1, 0.03).astype(np.float64)
+    P = lambda *v: np.array(v, dtype=np.float64)
+    a, b, c = P(0.06, 0.0, 0.0), P(0.09, 0.01, 0.0), P(0.06, 0.03, 0.02)
+    deg = np.stack([
+        np.stack([a, a, c]),                                  # a == b: the segment a-c
+        np.stack([b, b, b]),                                  # a point
+        np.stack([P(-0.06, 0, 0), P(-0.10, 0, 0), P(-0.08, 0, 0)]),      # collinear, c between a and b
+        np.stack([P(0, 0.06, 0), P(0, 0.08, 0), P(0, 0.11, 0)]),         # collinear, c beyond b
+        np.stack([P(0, -0.06, 0.01), P(0.02, -0.08, 0), P(0.02, -0.08, 0)]),   # b == c
+        np.stack([P(0, 0, 0.07), P(0.01, 0.02, 0.09), P(0, 0, 0.07)]),         # a == c
+    ])
+    fv = np.concatenate([reg, deg]).astype(np.float32)
+    nreg = reg.shape[0]
+    N = 40000
+    centres = fv[nreg:].astype(np.float64).mean(1)
+    pts = np.concatenate([centres[rng.integers(0, len(deg), N // 2)] + rng.normal(size=(N // 2, 3)) * 0.01,
+                          rng.normal(size=(N - N // 2, 3)) * 0.06]).astype(np.float32)
+
+    def seg_d2(p, u, v):
+        d = v - u
+        L2 = (d * d).sum()
+        t = np.clip(((p - u) @ d) / L2, 0.0, 1.0) if L2 > 0 else np.zeros(len(p))
+        q = u + t[:, None] * d
+        return ((p - q) ** 2).sum(1), q
+
+    p64, f64 = pts.astype(np.float64), fv.astype(np.float64)
+    od2, _, _, _ = osdf.compute_sdf(torch.tensor(p64[:3000]), torch.tensor(f64[:nreg]))
+    best = od2.numpy().copy()
+    from_deg = np.zeros(3000, dtype=bool)
+    for t in f64[nreg:]:
+        for u, v in ((t[0], t[1]), (t[0], t[2]), (t[1], t[2])):
+            d2s, _ = seg_d2(p64[:3000], u, v)
+            from_deg |= d2s < best
+            best = np.minimum(best, d2s)
+    assert from_deg.mean() > 0.2  # the degenerate faces do decide a good share of the queries
+    pd, fd = torch.tensor(pts, device="cuda"), torch.tensor(fv, device="cuda")
+    for route in ("hierarchy", "loop"):
+        d2, sg, nrm, cls = gq.ops.compute_sdf(pd, fd) if route == "hierarchy" else torch.ops.graspqp_amd.compute_sdf(pd, fd)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(np.sqrt(d2.cpu().numpy()[:3000]), np.sqrt(best), rtol=2e-5, atol=2e-7, err_msg=route)
+        far = from_deg & (best > 1e-8)
+        assert (sg.cpu().numpy()[:3000][far] == 1).all(), route
+        diff = (pd - cls)[:3000].cpu().numpy()
+        np.testing.assert_allclose(nrm.cpu().numpy()[:3000][far], diff[far] / np.linalg.norm(diff[far], axis=1, keepdims=True),
+                                   atol=1e-4, err_msg=route)
+        assert torch.isfinite(d2).all() and torch.isfinite(nrm).all()
+    assert (id(fd), "bvh") in gq.ops._MESH_CACHE
+
+
 def test_compute_sdf_mesh_cache_follows_the_face_verts_tensor(gq):
     """compute_sdf keeps the acceleration data of a mesh (>= 1024 faces) while the caller's face_verts tensor is alive and
     unmodified: a second call reuses it, an in-place change of the tensor rebuilds it, a dead tensor drops its entry; the

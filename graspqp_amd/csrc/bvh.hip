@@ -1,7 +1,7 @@
 // TorchSDF-shaped mesh distance query for MANY points against one mesh: one query per lane, exact closest face through an
 // implicit 4-ary bounding-volume hierarchy (reference call sites: core/hand_model.py:914-953 -- batch * 2500 object surface
 // points against every hand-link mesh, N = 640 000 at BASELINE configs[1] -- and core/object_model.py:217-220 for large
-// batches).  Replaces the per-lane loop over ALL faces (gq_sdf_points_kernel: F x 45 VALU operations per query).
+// batches).  Replaces the per-lane loop over ALL faces (gq_sdf_points_kernel: F x 36 VALU operations per query).
 //
 // Layout (one contiguous blob of 16-byte words, built once per mesh on the host, staged into LDS by every block when it fits):
 //   faces are Morton-sorted; level 0 groups 4 consecutive faces ("leaf"), level k groups 4 nodes of level k-1, until at most
@@ -13,6 +13,11 @@
 // ranking distance (gq_tri_rank) is evaluated.  Ties go to the smallest ORIGINAL face index (the face loop's rule).  The
 // winner is finished exactly (gq_tri_finish), like in every other SDF kernel here.
 // Wavefront cost = the slowest lane's path; measured in bench.py's plugin_surface block.
+// LDS residency is what makes the per-lane gathers cheap: blobs up to 156 KB (~1 120 faces) are staged (one 1024-thread block
+// per CU above 80 KB), larger ones are walked from L2 at about twice the cost per query.  On the reference's per-link call
+// shape (far-field queries) the hierarchy beats the face loop and the cluster search at every mesh size either way; for many
+// CONTACT-like queries (within centimetres of a 9 k-face surface) the cluster search is the faster one
+// (tools/ab_contact_routes.py, profiles/r03_ab_sdf_routes.txt) -- the reference never issues such a call with >= 32 768 queries.
 #include "tri.h"
 
 #include <algorithm>
@@ -100,22 +105,26 @@ struct GqBvhVisit<0> {
   }
 };
 
-// persistent blocks: the blob is staged once per block (LDS = true), then the block strides over 512-point chunks
+// persistent blocks: the blob is staged once per block (LDS = true), then the block strides over chunks of blockDim.x points.
+// Blocks have 512 threads while two or more of them fit a CU's 160 KB of LDS beside their blobs, 1024 threads (one block per
+// CU, the same 16 wavefronts) for the larger blobs up to GQ_BVH_LDS_MAX.
 #ifndef GQ_BVH_MIN_BLOCKS
 #define GQ_BVH_MIN_BLOCKS 1  // min wavefronts per SIMD; A/B: 6 caps the kernel at 80 VGPRs (three 512-thread blocks per CU)
 #endif
+#define GQ_BVH_LDS_MAX (156 * 1024)
 template <int DEPTH, bool LDS>
-__global__ __launch_bounds__(512, GQ_BVH_MIN_BLOCKS) void gq_sdf_bvh_kernel(GqBvhArgs g) {
+__global__ __launch_bounds__(1024, GQ_BVH_MIN_BLOCKS) void gq_sdf_bvh_kernel(GqBvhArgs g) {
   extern __shared__ float4 gq_bvh_sh[];
   const float4* base = g.blob;
+  const unsigned nthr = blockDim.x;
   if (LDS) {
-    for (unsigned i = threadIdx.x; i < g.words; i += 512) gq_bvh_sh[i] = g.blob[i];
+    for (unsigned i = threadIdx.x; i < g.words; i += nthr) gq_bvh_sh[i] = g.blob[i];
     __syncthreads();
     base = gq_bvh_sh;
   }
-  const long long nchunk = (g.N + 511) / 512;
+  const long long nchunk = (g.N + nthr - 1) / nthr;
   for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-    const long long q = ch * 512 + threadIdx.x;
+    const long long q = ch * nthr + threadIdx.x;
     const bool ok = q < g.N;
     const long long qq = ok ? q : g.N - 1;
     const gq3 p = gq_mk(g.points[qq * 3 + 0], g.points[qq * 3 + 1], g.points[qq * 3 + 2]);
@@ -425,9 +434,14 @@ int gq_sdf_forward_bvh(const gqBvh* b, const float* points, int64_t n_points, fl
   a.normal = normal;
   a.closest = closest;
   const size_t bytes = b->words * 16;
-  const bool lds = bytes <= 64 * 1024;  // at least two 512-thread blocks per CU (160 KB of LDS)
   const bool sorted = gq_bvh_sorted_ != 0 && n_points >= 4 * GQ_BVH_CHUNK;
-  const long long per_chunk = sorted ? GQ_BVH_CHUNK : 512;
+  // LDS-resident while the blob fits: two or more 512-thread blocks per CU up to 80 KB, one 1024-thread block per CU above
+  // (a hierarchy walked from global memory costs about twice as much per query: 140 us at 456 faces in LDS against 256 us at
+  // 502 faces from L2 on the reference's per-link call shape, profiles/r03_ab_sdf_routes.txt); the A/B sorted variant keeps
+  // its 64 KB limit
+  const bool lds = b->depth <= 5 && bytes <= (sorted ? (size_t)64 * 1024 : (size_t)GQ_BVH_LDS_MAX);
+  const unsigned threads = (!sorted && lds && bytes > 80 * 1024) ? 1024u : 512u;
+  const long long per_chunk = sorted ? GQ_BVH_CHUNK : (long long)threads;
   const long long nchunk = (n_points + per_chunk - 1) / per_chunk;
   const size_t stat = sorted ? 5 * 1024 : 0;  // static LDS of the sorted kernel (histogram + permutation)
   const int per_cu = lds ? (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (bytes + stat))) : 4;
@@ -435,16 +449,27 @@ int gq_sdf_forward_bvh(const gqBvh* b, const float* points, int64_t n_points, fl
   hipStream_t st = (hipStream_t)stream;
 #define GQ_BVH_LAUNCH(D, L)                                                                                                   \
   do {                                                                                                                        \
-    if (sorted) hipLaunchKernelGGL((gq_sdf_bvh_sorted_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a, b->centre[0], \
-                                   b->centre[1], b->centre[2]);                                                               \
-    else hipLaunchKernelGGL((gq_sdf_bvh_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a);                        \
+    if (sorted) {                                                                                                             \
+      hipLaunchKernelGGL((gq_sdf_bvh_sorted_kernel<D, L>), dim3(grid), dim3(512), (L) ? bytes : 0, st, a, b->centre[0],       \
+                         b->centre[1], b->centre[2]);                                                                         \
+    } else {                                                                                                                  \
+      if ((L) && bytes > 64 * 1024) { /* more dynamic LDS than the 64 KB a kernel may use without asking */                    \
+        static bool raised = false;                                                                                           \
+        if (!raised) {                                                                                                        \
+          GQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gq_sdf_bvh_kernel<D, L>),                           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GQ_BVH_LDS_MAX));                      \
+          raised = true;                                                                                                      \
+        }                                                                                                                     \
+      }                                                                                                                       \
+      hipLaunchKernelGGL((gq_sdf_bvh_kernel<D, L>), dim3(grid), dim3(threads), (L) ? bytes : 0, st, a);                       \
+    }                                                                                                                         \
   } while (0)
   switch (b->depth) {
     case 1: if (lds) GQ_BVH_LAUNCH(1, true); else GQ_BVH_LAUNCH(1, false); break;
     case 2: if (lds) GQ_BVH_LAUNCH(2, true); else GQ_BVH_LAUNCH(2, false); break;
     case 3: if (lds) GQ_BVH_LAUNCH(3, true); else GQ_BVH_LAUNCH(3, false); break;
     case 4: if (lds) GQ_BVH_LAUNCH(4, true); else GQ_BVH_LAUNCH(4, false); break;
-    case 5: GQ_BVH_LAUNCH(5, false); break;
+    case 5: if (lds) GQ_BVH_LAUNCH(5, true); else GQ_BVH_LAUNCH(5, false); break;
     case 6: GQ_BVH_LAUNCH(6, false); break;
     case 7: GQ_BVH_LAUNCH(7, false); break;
     default: GQ_BVH_LAUNCH(8, false); break;

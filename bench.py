@@ -484,18 +484,11 @@ def rank_main(args):
         }
         if per_rank is not None:
             res["per_rank_evals_per_s"] = per_rank
-        if world == 1 and not args.no_cpu_baseline:
-            # SURVEY 8d: the CPU port on configs 1 and 2 of BASELINE.json; `cpu_baseline` = the metric's configuration
-            res["cpu_baseline"] = cpu_baseline(spec, fvs[0], sps[0], args.n_contact, args.cpu_rows, args.cpu_reps,
-                                               "BASELINE configs[1] sample (Allegro, superquadric mesh)")
-            sph = meshes.icosphere(3, 0.05)
-            res["cpu_baseline_config0"] = cpu_baseline(get_hand_spec("allegro"), sph,
-                                                       meshes.surface_points(sph, 2500, oversample=4, seed=42), 4, 4,
-                                                       args.cpu_reps, "BASELINE configs[0] (Allegro, sphere, batch 4, n_contact 4)")
         want_plugin = args.plugin_surface == 1 or (args.plugin_surface < 0 and world == 1 and is_cfg2 and args.energy_type == "graspqp")
         if want_plugin:
             # the reference's plugin surface on the same workload (what an unchanged scripts/fit.py calls), after the timed
-            # region; tools/plugin_surface.py documents the shapes
+            # region and BEFORE the CPU baseline (its class-surface loop is bound by host time per call: measured 0.25 M
+            # evals/s right after the 16-thread oracle run against 0.40 M before it); tools/plugin_surface.py documents the shapes
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import plugin_surface
@@ -506,6 +499,14 @@ def rank_main(args):
                 res["plugin_surface"]["stepper_evals_per_s"] = res["value"]
             except Exception as e:  # diagnostics must never cost the bench line
                 res["plugin_surface"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            # SURVEY 8d: the CPU port on configs 1 and 2 of BASELINE.json; `cpu_baseline` = the metric's configuration
+            res["cpu_baseline"] = cpu_baseline(spec, fvs[0], sps[0], args.n_contact, args.cpu_rows, args.cpu_reps,
+                                               "BASELINE configs[1] sample (Allegro, superquadric mesh)")
+            sph = meshes.icosphere(3, 0.05)
+            res["cpu_baseline_config0"] = cpu_baseline(get_hand_spec("allegro"), sph,
+                                                       meshes.surface_points(sph, 2500, oversample=4, seed=42), 4, 4,
+                                                       args.cpu_reps, "BASELINE configs[0] (Allegro, sphere, batch 4, n_contact 4)")
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

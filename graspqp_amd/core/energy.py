@@ -79,17 +79,18 @@ class _FusedTerms(torch.autograd.Function):
         return ghp + g_j.unsqueeze(-1) * g_pose, None, None, None, None
 
 
-def _fusable(hand_model, object_model, energy_fnc, method):
+def _fusable(hand_model, object_model, energy_fnc, method, energy_names):
     from ..metrics.ops.registry import SpanMetricWrapper
 
     return (FUSED and not ops._ROUTE["dispatcher"] and not torch.compiler.is_compiling() and isinstance(energy_fnc, SpanMetricWrapper)
+            and "E_manipulativity" not in energy_names  # its directions carry a gradient to `distance`
             and method in ("gendexgrasp", "dexgraspnet") and getattr(object_model, "_meshset", None) is not None
             and object_model.surface_points_each is not None and getattr(hand_model, "_fk_ws", None) is not None)
 
 
 def calculate_energy(hand_model, object_model, energy_fnc=None, energy_names=[], method="gendexgrasp", svd_gain=0.1):
     losses = {}
-    if _fusable(hand_model, object_model, energy_fnc, method):
+    if _fusable(hand_model, object_model, energy_fnc, method, energy_names):
         object_model.attach(hand_model)
         (losses["E_dis"], losses["E_fc"], losses["E_joints"], losses["E_pen"], losses["E_spen"], distance, contact_normal,
          _lambda) = _FusedTerms.apply(hand_model.hand_pose, hand_model, object_model, energy_fnc.fc_config(svd_gain=svd_gain),
@@ -130,16 +131,9 @@ def _extra_terms(losses, hand_model, energy_names, distance, contact_normal):
         losses["E_wall"] = z_height.abs().sum(-1)
 
     if "E_manipulativity" in energy_names:
-        # energy.py:80-87.  Value only: the reference differentiates it through the Jacobian and the pseudo-inverse, but
-        # scripts/fit.py cannot select it (no weight for it: fit.py:363-371 raises on the unknown name), so no backward here
-        if hand_model.hand_pose.requires_grad:
-            import warnings
-
-            warnings.warn("graspqp_amd: E_manipulativity is VALUE-ONLY (no gradient reaches hand_pose through it; the reference "
-                          "differentiates it through the contact Jacobian and its pseudo-inverse, core/energy.py:80-87). "
-                          "Weighting it in an energy that is back-propagated adds nothing to the gradient.", RuntimeWarning,
-                          stacklevel=3)
+        # energy.py:80-87: mean squared contact velocity the joints cannot produce when the contacts move along
+        # normal * max(|distance|, 5 mm); differentiable (ops.joint_velocity_residuals: analytic kinematic Hessian)
         E_jacobian = hand_model.get_manipulability(
-            contact_normal * distance.detach().unsqueeze(-1).abs().clamp(min=5e-3), hand_model.contact_point_indices)
+            contact_normal * distance.unsqueeze(-1).abs().clamp(min=5e-3), hand_model.contact_point_indices)
         losses["E_manipulativity"] = E_jacobian.mean(-1)
     return losses

@@ -220,6 +220,12 @@ class HandModel:
                                      .unsqueeze(0).expand(B, -1))
         idx = contact_point_indices.contiguous()
         n = idx.shape[1]
+        if coupled and not return_ee_vel and torch.is_grad_enabled() and (
+                self.hand_pose.requires_grad or moving_directions.requires_grad):
+            # differentiable route (E_manipulativity, core/energy.py:80-87): gradient to the joint angles through the contact
+            # Jacobian, to the root rotation through R' d, and to the directions themselves
+            return ops.joint_velocity_residuals(self.hand_pose, moving_directions.to(torch.float32), self._hand, idx,
+                                                self.global_rotation, self.current_status, self._fk_ws)
         # link transforms / joint frames of the CURRENT pose (written by the last set_parameters)
         jc = ops.contact_jacobian(self._hand, idx, self.current_status, self._fk_ws)  # (B,n,3,J)
         R = self.global_rotation.detach()

@@ -98,6 +98,105 @@ __global__ __launch_bounds__(GQ_WAVE) void gq_jacobian_kernel(GqJacArgs g) {
   }
 }
 
+// Backward of gq_contact_jacobian w.r.t. the joint angles: g_theta[k] = sum_{contact i, joint j} G_ij . dJ_ij/dtheta_k with the
+// kinematic Hessian of the tree in closed form.  J_ij = a_j x (x_i - p_j) (revolute j on the path base -> contact i) or a_j
+// (prismatic); for another joint k on that path
+//   k above j (nearer the base):  everything below k turns about a_k (revolute k): dJ_ij = a_k x J_ij; a prismatic k shifts
+//                                 p_j and x_i alike: 0
+//   k == j, revolute:             only x_i turns: dJ_ij = a_j x (a_j x (x_i - p_j))
+//   k below j (nearer the contact): only x_i moves, by a_k x (x_i - p_k) (revolute k) or a_k (prismatic k): dJ_ij = a_j x dx_i
+//                                 for a revolute j, 0 for a prismatic one
+// (what autograd through the pytorch_kinematics Jacobian computes in the reference, core/energy.py:80-87 via
+// hand_model.py:1155-1218).  One wavefront per row, lane k = tree joint k; coupled hands: G's actuated columns are spread to the
+// tree joints with C and the tree gradient is folded back with C' (J_act = J_tree C).
+struct GqJacBwdArgs {
+  gqHand h;
+  const float* node_W;   // (B,J,12)
+  const float* link_T;   // (B,L,12)
+  const int64_t* idx;    // (B,n)
+  const float* G;        // (B,n,3,JA)
+  int B, n;
+  float* g_theta;        // (B,JA)
+};
+
+__global__ __launch_bounds__(GQ_WAVE) void gq_contact_jacobian_bwd_kernel(GqJacBwdArgs g) {
+  __shared__ int s_parent[GQ_WAVE], s_type[GQ_WAVE];
+  __shared__ float s_a[GQ_WAVE * 3], s_p[GQ_WAVE * 3], s_G[GQ_WAVE * 3], s_acc[GQ_WAVE];
+  const gqHand& h = g.h;
+  const int row = blockIdx.x, lane = gq_lane();
+  gq3 ak = gq_mk(0, 0, 0), pk = gq_mk(0, 0, 0);
+  int tk = 0;
+  if (lane < h.J) {
+    const GqT W = gq_t_load(g.node_W + ((size_t)row * h.J + lane) * 12);
+    ak = gq_t_rot(W, gq_mk(h.node_axis[lane * 3], h.node_axis[lane * 3 + 1], h.node_axis[lane * 3 + 2]));
+    pk = gq_t_pos(W);
+    tk = h.node_type[lane];
+    s_parent[lane] = h.node_parent[lane];
+    s_type[lane] = tk;
+    s_a[lane * 3] = ak.x; s_a[lane * 3 + 1] = ak.y; s_a[lane * 3 + 2] = ak.z;
+    s_p[lane * 3] = pk.x; s_p[lane * 3 + 1] = pk.y; s_p[lane * 3 + 2] = pk.z;
+  }
+  gq_wave_sync();
+  float acc = 0.0f;
+  for (int c = 0; c < g.n; ++c) {  // wave-uniform loop
+    const int ci = (int)g.idx[(size_t)row * g.n + c];
+    const int l = h.cand_link[ci];
+    const gq3 x = gq_t_apply(gq_t_load(g.link_T + ((size_t)row * h.L + l) * 12),
+                             gq_mk(h.cand_pos[ci * 3], h.cand_pos[ci * 3 + 1], h.cand_pos[ci * 3 + 2]));
+    // G of this contact per TREE joint (lane j)
+    gq3 Gj = gq_mk(0, 0, 0);
+    if (lane < h.J) {
+      const float* Gc = g.G + ((size_t)row * g.n + c) * 3 * h.JA;
+      if (h.coup) {
+        for (int a = 0; a < h.JA; ++a) {
+          const float cj = h.coup[lane * h.JA + a];
+          Gj.x = fmaf(cj, Gc[a], Gj.x);
+          Gj.y = fmaf(cj, Gc[h.JA + a], Gj.y);
+          Gj.z = fmaf(cj, Gc[2 * h.JA + a], Gj.z);
+        }
+      } else {
+        Gj = gq_mk(Gc[lane], Gc[h.JA + lane], Gc[2 * h.JA + lane]);
+      }
+    }
+    gq_wave_sync();
+    s_G[lane * 3] = Gj.x; s_G[lane * 3 + 1] = Gj.y; s_G[lane * 3 + 2] = Gj.z;
+    gq_wave_sync();
+    bool on_path = false;
+    for (int nd = h.link_node[l]; nd >= 0; nd = s_parent[nd]) on_path |= (nd == lane);
+    if (on_path && lane < h.J) {
+      bool passed = false;  // walking from the contact's link towards the base: have we passed joint `lane` yet?
+      for (int j = h.link_node[l]; j >= 0; j = s_parent[j]) {
+        const gq3 aj = gq_mk(s_a[j * 3], s_a[j * 3 + 1], s_a[j * 3 + 2]);
+        const gq3 pj = gq_mk(s_p[j * 3], s_p[j * 3 + 1], s_p[j * 3 + 2]);
+        const gq3 Gv = gq_mk(s_G[j * 3], s_G[j * 3 + 1], s_G[j * 3 + 2]);
+        const bool jrev = s_type[j] == 1;
+        gq3 dJ = gq_mk(0, 0, 0);
+        if (j == lane) {
+          passed = true;
+          if (jrev) dJ = gq_cross(aj, gq_cross(aj, x - pj));
+        } else if (!passed) {  // j lies between joint `lane` and the contact: `lane` is above j
+          if (tk == 1) dJ = gq_cross(ak, jrev ? gq_cross(aj, x - pj) : aj);
+        } else {               // j lies above joint `lane`
+          if (jrev) dJ = gq_cross(aj, tk == 1 ? gq_cross(ak, x - pk) : ak);
+        }
+        acc += gq_dot(Gv, dJ);
+      }
+    }
+  }
+  if (h.coup) {
+    gq_wave_sync();
+    s_acc[lane] = lane < h.J ? acc : 0.0f;
+    gq_wave_sync();
+    if (lane < h.JA) {
+      float v = 0.0f;
+      for (int j = 0; j < h.J; ++j) v = fmaf(h.coup[j * h.JA + lane], s_acc[j], v);
+      g.g_theta[(size_t)row * h.JA + lane] = v;
+    }
+  } else if (lane < h.JA) {
+    g.g_theta[(size_t)row * h.JA + lane] = acc;
+  }
+}
+
 // theta = (J'J + lambda I)^-1 J' d  for one row per wavefront; A and its Cholesky factor in fp64 (LDS)
 #define GQ_JV_MAXJ 64
 struct GqJvArgs {
@@ -263,6 +362,28 @@ int gq_contact_jacobian(const gqHand* h, const int64_t* contact_idx, int64_t bat
   a.n = n_contact;
   a.out = jac;
   hipLaunchKernelGGL(gq_jacobian_kernel<false>, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
+  GQ_LAUNCH_CHECK();
+  return GQ_OK;
+}
+
+int gq_contact_jacobian_backward(const gqHand* h, const int64_t* contact_idx, int64_t batch, int n_contact, const float* link_T,
+                                 const float* grad_jac, float* grad_theta, const void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  GQ_REQUIRE(h && contact_idx && link_T && grad_jac && grad_theta && workspace, "contact_jacobian_backward: null pointer");
+  GQ_REQUIRE(batch > 0 && n_contact > 0 && h->J <= GQ_WAVE, "contact_jacobian_backward: bad sizes (B=%lld, n=%d, J=%d)",
+             (long long)batch, n_contact, h->J);
+  GQ_REQUIRE(workspace_bytes >= (size_t)batch * h->J * 12 * sizeof(float),
+             "contact_jacobian_backward: not an FK workspace of this batch");
+  GqJacBwdArgs a{};
+  a.h = *h;
+  a.node_W = (const float*)workspace;
+  a.link_T = link_T;
+  a.idx = contact_idx;
+  a.G = grad_jac;
+  a.B = (int)batch;
+  a.n = n_contact;
+  a.g_theta = grad_theta;
+  hipLaunchKernelGGL(gq_contact_jacobian_bwd_kernel, dim3((unsigned)batch), dim3(GQ_WAVE), 0, (hipStream_t)stream, a);
   GQ_LAUNCH_CHECK();
   return GQ_OK;
 }

@@ -847,6 +847,52 @@ def joint_velocities(jac, directions, Rg=None, damping=1e-3):
     return theta, res, ee
 
 
+class _JointVelocityResiduals(torch.autograd.Function):
+    """residuals (B,3n) = (J theta - d_h)^2 with theta = pinv_damped(J) d_h, d_h = R' d (hand_model.py:1155-1218, coupled form),
+    differentiable w.r.t. hand_pose (joint angles through the contact Jacobian -- analytic kinematic Hessian,
+    gq_contact_jacobian_backward -- and the root rotation through d_h) and w.r.t. the moving directions d: what autograd
+    through pytorch_kinematics gives the reference for E_manipulativity (core/energy.py:80-87).  The kinematic state
+    (link transforms, FK workspace, root rotation) is the one of ``hand_pose``, passed in detached."""
+
+    @staticmethod
+    def forward(ctx, hand_pose, directions, hand, idx, Rg, LT, ws, damping):
+        hp, d, R = _c(hand_pose.detach()), _c(directions.detach()), _c(Rg.detach())
+        ix = _c(idx, torch.int64)
+        B, n = ix.shape
+        jc = contact_jacobian(hand, ix, LT, ws).reshape(B, 3 * n, hand.J)
+        theta, res, _ = joint_velocities(jc, d.reshape(B, 3 * n), R, damping)
+        d_h = (R.transpose(1, 2).unsqueeze(1) @ d.unsqueeze(-1)).squeeze(-1).reshape(B, 3 * n)
+        r = (jc @ theta.unsqueeze(-1)).squeeze(-1) - d_h  # signed residual, hand frame
+        ctx.save_for_backward(hp, d, R, ix, _c(LT.detach()), ws, jc, theta, r)
+        ctx.hand, ctx.damping = hand, damping
+        ctx.mark_non_differentiable(theta)
+        return theta, res
+
+    @staticmethod
+    def backward(ctx, _g_theta, g_res):
+        hp, d, R, ix, LT, ws, jc, theta, r = ctx.saved_tensors
+        hand = ctx.hand
+        B, n = ix.shape
+        g = 2.0 * g_res * r                                           # d E / d r
+        u, _, _ = joint_velocities(jc, g, None, ctx.damping)          # (J'J + lambda I)^-1 J' g
+        w = g - (jc @ u.unsqueeze(-1)).squeeze(-1)                    # (I - J M^-1 J') g
+        GJ = (w.unsqueeze(-1) * theta.unsqueeze(1) - r.unsqueeze(-1) * u.unsqueeze(1)).contiguous()  # d E / d J  (B,3n,J)
+        g_dh = (-w).reshape(B, n, 3)                                  # d E / d d_h
+        g_d = (R.unsqueeze(1) @ g_dh.unsqueeze(-1)).squeeze(-1)       # d_h = R' d
+        gR = (d.unsqueeze(-1) * g_dh.unsqueeze(-2)).sum(1).contiguous()  # (B,3,3): dE/dR[a,c] = sum_i d[i,a] g_dh[i,c]
+        g_th = torch.empty(B, hand.J, device=hp.device)
+        _C.call("gq_contact_jacobian_backward", hand.handle, _C.i64(ix), ctypes.c_int64(B), n, _C.f32(LT), _C.f32(GJ),
+                _C.f32(g_th), _C.ptr(ws), ws.numel(), _C.stream_ptr())
+        ghp = _fk_backward(hand, hp, ix, R, LT, ws, None, None, None, None, None, gR).clone()
+        ghp[:, hp.shape[1] - hand.J:] += g_th
+        return ghp, g_d, None, None, None, None, None, None
+
+
+def joint_velocity_residuals(hand_pose, directions, hand: HandHandle, idx, Rg, LT, ws, damping=1e-3):
+    """-> (theta (B,J), residuals (B,3n)); see _JointVelocityResiduals."""
+    return _JointVelocityResiduals.apply(hand_pose, directions, hand, idx, Rg, LT, ws, float(damping))
+
+
 def root_pose_wxyz(hand_pose):
     """(B,7) = [translation, unit quaternion (w,x,y,z)] of hand_pose[:, :9] (fit.py:260-263)."""
     hp = _c(hand_pose.detach())

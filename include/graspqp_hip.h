@@ -295,6 +295,12 @@ int gq_link_jacobian(const gqHand* h, int64_t batch, const float* link_T /* (B,L
 int gq_contact_jacobian(const gqHand* h, const int64_t* contact_idx /* (B,n) */, int64_t batch, int n_contact,
                         const float* link_T, float* jac /* (B,n,3,JA) */, const void* workspace, size_t workspace_bytes,
                         void* stream);
+/* d (sum_ij G_ij . J_ij) / d theta for the contact Jacobian above: grad_jac (B,n,3,JA) -> grad_theta (B,JA), the kinematic
+ * Hessian of the tree in closed form (what autograd through the Jacobian gives the reference for E_manipulativity,
+ * core/energy.py:80-87 via hand_model.py:1155-1218).  Same link_T / workspace as gq_contact_jacobian.                     */
+int gq_contact_jacobian_backward(const gqHand* h, const int64_t* contact_idx /* (B,n) */, int64_t batch, int n_contact,
+                                 const float* link_T, const float* grad_jac /* (B,n,3,JA) */, float* grad_theta /* (B,JA) */,
+                                 const void* workspace, size_t workspace_bytes, void* stream);
 int gq_joint_velocities(const float* jac, const float* directions, const float* Rg /* (B,9) or NULL */, int64_t batch,
                         int m, int n_dofs, float damping, float* theta /* (B,n_dofs) */, float* residual /* or NULL */,
                         float* ee_vel /* or NULL */, void* stream);

@@ -184,7 +184,8 @@ def test_annealing_dexgraspnet_matches_reference_optimizer(gq, golden_dir):
 @pytest.mark.parametrize("tag,n", [("allegro_sphere_b4_n4", 4), ("allegro_sq_b6_n12", 12)])
 def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     """E_prior and E_wall (core/energy.py:68-78, selectable with --w_prior / --w_wall) through calculate_energy against
-    the fixture produced by the reference's own energy.py; E_manipulativity is value-only (fit.py cannot select it)."""
+    the fixture produced by the reference's own energy.py; E_manipulativity (fit.py cannot select it) in value and gradient
+    against the oracle's restatement."""
     from graspqp_amd.core.energy import calculate_energy
     from graspqp_amd.core.hand_model import HandModel
     from graspqp_amd.core.object_model import ObjectModel
@@ -202,8 +203,7 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     hm.set_parameters(hp, torch.tensor(g["contact_idx"]).cuda())
     fn = GF.create(GF.MetricType.GRASPQP, {"friction": 0.2, "max_limit": 20.0, "n_cone_vecs": 4})
     names = ["E_dis", "E_fc", "E_pen", "E_spen", "E_joints", "E_prior", "E_wall", "E_manipulativity"]
-    with pytest.warns(RuntimeWarning, match="VALUE-ONLY"):  # a differentiable pose + this term: no silent zero gradient
-        losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
+    losses = calculate_energy(hm, om, energy_fnc=fn, energy_names=names, svd_gain=0.1)
     np.testing.assert_allclose(losses["E_prior"].detach().cpu().numpy(), g["opt_E_prior"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(losses["E_wall"].detach().cpu().numpy(), g["opt_E_wall"], rtol=1e-5, atol=1e-6)
     assert losses["E_manipulativity"].shape == (n_obj * be,) and torch.isfinite(losses["E_manipulativity"]).all()
@@ -217,7 +217,26 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     oh.set_parameters(torch.tensor(g["opt_hand_pose"], dtype=torch.float64), torch.tensor(g["contact_idx"]))
     dist_o, cn_o = oo.cal_distance(oh.contact_points)
     _, res_o = oexp.get_req_joint_velocities(oh, cn_o * dist_o.unsqueeze(-1).abs().clamp(min=5e-3), oh.contact_point_indices)
-    np.testing.assert_allclose(losses["E_manipulativity"].cpu().numpy(), res_o.mean(-1).numpy(), rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(losses["E_manipulativity"].detach().cpu().numpy(), res_o.mean(-1).numpy(), rtol=2e-3, atol=1e-9)
+    # ... and its GRADIENT (joint angles through the contact Jacobian -- kinematic Hessian --, root rotation through R' d,
+    # contact points through |distance|) against autograd through the oracle's restatement in fp64, under a non-uniform
+    # upstream; the reference gets it from autograd through pytorch_kinematics (core/energy.py:80-87)
+    up = torch.linspace(0.5, 2.0, n_obj * be)
+    (gm,) = torch.autograd.grad((losses["E_manipulativity"] * up.cuda()).sum(), hm.hand_pose, retain_graph=True)
+    hm.hand_pose.grad = None  # (hand_pose retains its gradient: the call above left this term's there)
+    oh2 = omodels.OracleHand(spec, torch.float64)
+    hp64 = torch.tensor(g["opt_hand_pose"], dtype=torch.float64).requires_grad_()
+    oh2.set_parameters(hp64, torch.tensor(g["contact_idx"]))
+    dist2, cn2 = oo.cal_distance(oh2.contact_points)
+    _, res2 = oexp.get_req_joint_velocities(oh2, cn2.detach() * dist2.unsqueeze(-1).abs().clamp(min=5e-3), oh2.contact_point_indices)
+    (go,) = torch.autograd.grad((res2.mean(-1) * up.double()).sum(), hp64)
+    gm, go = gm.cpu().double().numpy(), go.numpy()
+    assert np.linalg.norm(go) > 0 and np.linalg.norm(go[:, 9:]) > 0 and np.linalg.norm(go[:, 3:9]) > 0
+    print("E_manipulativity gradient rel err:", np.linalg.norm(gm - go) / np.linalg.norm(go),
+          "joints", np.linalg.norm(gm[:, 9:] - go[:, 9:]) / np.linalg.norm(go[:, 9:]),
+          "rotation", np.linalg.norm(gm[:, 3:9] - go[:, 3:9]) / np.linalg.norm(go[:, 3:9]),
+          "translation", np.linalg.norm(gm[:, :3] - go[:, :3]) / max(np.linalg.norm(go[:, :3]), 1e-30))
+    assert np.linalg.norm(gm - go) <= 1e-3 * np.linalg.norm(go)
     (2.0 * losses["E_prior"] + 3.0 * losses["E_wall"]).sum().backward()
     gref = g["opt_grad"]
     assert np.linalg.norm(hm.hand_pose.grad.cpu().numpy() - gref) <= 1e-4 * np.linalg.norm(gref)
@@ -226,6 +245,55 @@ def test_optional_energy_terms_match_reference(gq, golden_dir, tag, n):
     hm2.set_parameters(hp.detach(), torch.tensor(g["contact_idx"]).cuda())
     sp = hm2.get_surface_points()
     assert sp.shape == (n_obj * be, 512, 3) and torch.isfinite(sp).all()
+
+
+@pytest.mark.parametrize("hand_name", ["allegro", "shadow_hand", "ability_hand", "panda", "schunk2"])
+def test_joint_velocity_residuals_gradient(gq, hand_name):
+    """get_req_joint_velocities (hand_model.py:1155-1218, coupled form) is differentiable: residuals = (J theta - R'd)^2 with the
+    damped pseudo-inverse, gradient to the joint angles through the contact Jacobian (closed-form kinematic Hessian,
+    gq_contact_jacobian_backward -- revolute and PRISMATIC joints, COUPLED tree joints folded with C), to the root rotation
+    through R'd and to the directions.  Against autograd through the oracle's restatement in fp64, random upstream."""
+    from graspqp_amd.core.hand_model import HandModel
+    from ref_cpu import export as oexp
+
+    spec = get_hand_spec(hand_name)
+    B, n = 6, 3 if hand_name in ("panda", "schunk2") else 5
+    g0 = torch.Generator().manual_seed(23)
+    t = torch.randn(B, 3, generator=g0, dtype=torch.float64) * 0.1
+    lo, hi = torch.tensor(spec.joints_lower, dtype=torch.float64), torch.tensor(spec.joints_upper, dtype=torch.float64)
+    th = lo + (hi - lo) * torch.rand(B, spec.n_dofs, generator=g0, dtype=torch.float64)
+    hp = torch.cat([t, torch.randn(B, 6, generator=g0, dtype=torch.float64), th], 1)
+    idx = torch.randint(spec.n_contact_candidates, (B, n), generator=g0)
+    md = torch.randn(B, n, 3, generator=g0, dtype=torch.float64) * 0.02
+    up = torch.rand(B, 3 * n, generator=g0, dtype=torch.float64) + 0.5
+    hm = HandModel(spec, "cuda")
+    hm.set_parameters(hp.float().cuda().requires_grad_(), idx.cuda())
+    mdc = md.float().cuda().requires_grad_()
+    theta, res = hm.get_req_joint_velocities(mdc, idx.cuda())
+    assert res.requires_grad and not theta.requires_grad and res.shape == (B, 3 * n)
+    (res * up.float().cuda()).sum().backward()
+    oh = omodels.OracleHand(spec, torch.float64)
+    hpo, mdo = hp.clone().requires_grad_(), md.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    th_o, res_o = oexp.get_req_joint_velocities(oh, mdo, idx)
+    (res_o * up).sum().backward()
+    np.testing.assert_allclose(theta.detach().cpu().numpy(), th_o.detach().numpy(), rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(res.detach().cpu().numpy(), res_o.detach().numpy(), rtol=2e-3, atol=1e-9)
+    gp, go = hm.hand_pose.grad.cpu().double().numpy(), hpo.grad.numpy()
+    assert np.abs(go[:, :3]).max() == 0 and np.abs(gp[:, :3]).max() == 0          # no dependence on the root translation
+    assert np.linalg.norm(go[:, 3:9]) > 0
+    if hand_name in ("panda", "schunk2"):  # prismatic fingers only: the contact Jacobian does not depend on the joint values
+        assert np.abs(go[:, 9:]).max() == 0 and np.abs(gp[:, 9:]).max() == 0
+    else:
+        assert np.linalg.norm(go[:, 9:]) > 0
+        assert np.linalg.norm(gp[:, 9:] - go[:, 9:]) <= 2e-3 * np.linalg.norm(go[:, 9:]), "joint angles"
+    assert np.linalg.norm(gp[:, 3:9] - go[:, 3:9]) <= 2e-3 * np.linalg.norm(go[:, 3:9]), "root rotation"
+    gd, gdo = mdc.grad.cpu().double().numpy(), mdo.grad.numpy()
+    assert np.linalg.norm(gd - gdo) <= 2e-3 * np.linalg.norm(gdo), "directions"
+    # without gradients asked for, the plain (value) route answers the same numbers
+    with torch.no_grad():
+        th2, res2 = hm.get_req_joint_velocities(md.float().cuda(), idx.cuda())
+    assert torch.equal(th2, theta.detach()) and torch.equal(res2, res.detach())
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -296,6 +296,74 @@ def test_joint_velocity_residuals_gradient(gq, hand_name):
     assert torch.equal(th2, theta.detach()) and torch.equal(res2, res.detach())
 
 
+def test_mixed_revolute_prismatic_tree(gq, tmp_path):
+    """A synthetic hand whose chains MIX joint types (none of the reference's hands does: they are all-revolute or all-
+    prismatic): base -r(z)-> a -p(x)-> b -r(y)-> c, and a second branch a -r(x)-> d -p(z)-> e, built from a URDF by
+    hands/spec.py.  Forward kinematics, contact Jacobian, and the gradient of the joint-velocity residuals (every branch
+    of the closed-form kinematic Hessian: a prismatic joint above / below a revolute one and vice versa) against the
+    oracle's restatement and autograd through it in fp64."""
+    import json
+
+    from graspqp_amd.core.hand_model import HandModel
+    from graspqp_amd.hands.spec import build_hand_spec
+    from ref_cpu import export as oexp
+
+    box = meshes.box() * 0.02  # (12,3,3) triangles of a small box
+    with open(tmp_path / "box.obj", "w") as f:
+        v = box.reshape(-1, 3)
+        for p in v:
+            f.write(f"v {p[0]} {p[1]} {p[2]}\n")
+        for i in range(len(box)):
+            f.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+    link = lambda n: (f'<link name="{n}"><collision><origin xyz="0.01 0 0.005" rpy="0 0 0.3"/><geometry><mesh filename="box.obj"/>'
+                      f'</geometry></collision></link>')
+    joint = lambda n, t, par, ch, xyz, rpy, ax, lo, hi: (
+        f'<joint name="{n}" type="{t}"><parent link="{par}"/><child link="{ch}"/><origin xyz="{xyz}" rpy="{rpy}"/>'
+        f'<axis xyz="{ax}"/><limit lower="{lo}" upper="{hi}"/></joint>')
+    urdf = ('<robot name="mixed">' + "".join(link(n) for n in ("base", "a", "b", "c", "d", "e"))
+            + joint("j_a", "revolute", "base", "a", "0.03 0 0.01", "0 0.2 0", "0 0 1", -1.0, 1.0)
+            + joint("j_b", "prismatic", "a", "b", "0.04 0.01 0", "0.1 0 0", "1 0 0", -0.02, 0.03)
+            + joint("j_c", "revolute", "b", "c", "0.03 0 0.02", "0 0 0.4", "0 1 0", -1.2, 1.2)
+            + joint("j_d", "revolute", "a", "d", "0 0.04 0", "0.3 0 0", "1 0 0", -0.8, 0.8)
+            + joint("j_e", "prismatic", "d", "e", "0.01 0.03 0", "0 0.2 0.1", "0 0 1", -0.01, 0.02) + "</robot>")
+    (tmp_path / "mixed.urdf").write_text(urdf)
+    rng = np.random.default_rng(4)
+    cinfo = {n: {"contact_candidates": (rng.normal(size=(3, 3)) * 0.01).tolist(),
+                 "normal_candidates": np.tile([[0.0, 0.0, 1.0]], (3, 1)).tolist()} for n in ("b", "c", "d", "e")}
+    (tmp_path / "cinfo.json").write_text(json.dumps(cinfo))
+    (tmp_path / "pen.json").write_text("{}")
+    spec = build_hand_spec("mixed", str(tmp_path / "mixed.urdf"), str(tmp_path), str(tmp_path / "pen.json"),
+                           str(tmp_path / "cinfo.json"), default_state=[0.0] * 5)
+    assert spec.n_dofs == 5 and spec.n_contact_candidates == 12
+    B, n = 7, 6
+    g0 = torch.Generator().manual_seed(3)
+    lo, hi = torch.tensor(spec.joints_lower, dtype=torch.float64), torch.tensor(spec.joints_upper, dtype=torch.float64)
+    th = lo + (hi - lo) * torch.rand(B, 5, generator=g0, dtype=torch.float64)
+    hp = torch.cat([torch.randn(B, 3, generator=g0, dtype=torch.float64) * 0.1, torch.randn(B, 6, generator=g0, dtype=torch.float64), th], 1)
+    idx = torch.randint(12, (B, n), generator=g0)
+    md = torch.randn(B, n, 3, generator=g0, dtype=torch.float64) * 0.02
+    up = torch.rand(B, 3 * n, generator=g0, dtype=torch.float64) + 0.5
+    hm = HandModel(spec, "cuda")
+    hm.set_parameters(hp.float().cuda().requires_grad_(), idx.cuda())
+    oh = omodels.OracleHand(spec, torch.float64)
+    hpo, mdo = hp.clone().requires_grad_(), md.clone().requires_grad_()
+    oh.set_parameters(hpo, idx)
+    np.testing.assert_allclose(hm.contact_points.detach().cpu().numpy(), oh.contact_points.detach().numpy(), rtol=1e-5, atol=2e-7)
+    jc = gq.ops.contact_jacobian(hm._hand, idx.cuda(), hm.current_status, hm._fk_ws).cpu().numpy()
+    np.testing.assert_allclose(jc, oexp.contact_jacobian(spec, th, idx).numpy(), rtol=1e-4, atol=2e-7)
+    mdc = md.float().cuda().requires_grad_()
+    theta, res = hm.get_req_joint_velocities(mdc, idx.cuda())
+    (res * up.float().cuda()).sum().backward()
+    th_o, res_o = oexp.get_req_joint_velocities(oh, mdo, idx)
+    (res_o * up).sum().backward()
+    np.testing.assert_allclose(res.detach().cpu().numpy(), res_o.detach().numpy(), rtol=2e-3, atol=1e-9)
+    gp, go = hm.hand_pose.grad.cpu().double().numpy(), hpo.grad.numpy()
+    assert (np.abs(go[:, 9:]).max(0) > 0).all()  # every joint, prismatic ones included, moves some Jacobian column
+    assert np.linalg.norm(gp[:, 9:] - go[:, 9:]) <= 2e-3 * np.linalg.norm(go[:, 9:]), "joint values"
+    assert np.linalg.norm(gp[:, 3:9] - go[:, 3:9]) <= 2e-3 * np.linalg.norm(go[:, 3:9]), "root rotation"
+    assert np.linalg.norm(mdc.grad.cpu().double().numpy() - mdo.grad.numpy()) <= 2e-3 * np.linalg.norm(mdo.grad.numpy())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # coupled-joint hands and grasp-type subsets (SURVEY 8f-4)
 # ---------------------------------------------------------------------------------------------------------------

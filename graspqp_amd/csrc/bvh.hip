@@ -440,7 +440,10 @@ int gq_sdf_forward_bvh(const gqBvh* b, const float* points, int64_t n_points, fl
   // 502 faces from L2 on the reference's per-link call shape, profiles/r03_ab_sdf_routes.txt); the A/B sorted variant keeps
   // its 64 KB limit
   const bool lds = b->depth <= 5 && bytes <= (sorted ? (size_t)64 * 1024 : (size_t)GQ_BVH_LDS_MAX);
-  const unsigned threads = (!sorted && lds && bytes > 80 * 1024) ? 1024u : 512u;
+#ifndef GQ_BVH_SMALL_THREADS
+#define GQ_BVH_SMALL_THREADS 512u  // A/B: 640 (two blocks = five wavefronts per SIMD for the <= 3-level hierarchies) is 20 % SLOWER
+#endif                             // on the 188 ... 232-face Allegro links (profiles/r03_ab_bvh_occupancy.txt): LDS-bound, not latency-bound
+  const unsigned threads = (!sorted && lds && bytes > 80 * 1024) ? 1024u : ((!sorted && lds && b->depth <= 3) ? GQ_BVH_SMALL_THREADS : 512u);
   const long long per_chunk = sorted ? GQ_BVH_CHUNK : (long long)threads;
   const long long nchunk = (n_points + per_chunk - 1) / per_chunk;
   const size_t stat = sorted ? 5 * 1024 : 0;  // static LDS of the sorted kernel (histogram + permutation)
